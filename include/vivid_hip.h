@@ -1,0 +1,244 @@
+/*
+ * vivid_hip.h — C ABI of libvivid_hip.so: MI355X (gfx950) kernels for the VIVID
+ * pose-conditioned UNet denoiser.
+ *
+ * The reference (danielcodelavin/vivid) has no native layer: its device boundary
+ * is the set of stock PyTorch op call sites inside training/models.py
+ * (SURVEY.md 2.3).  Each entry point below replaces one group of those call
+ * sites; the reference lines are cited per function.  All tensors are raw device
+ * pointers to fp32 data; activations are NHWC ([rows, H, W, C], C fastest) and
+ * every pointer passed as an NHWC source must be 16-byte aligned with C % 4 == 0.
+ * Nothing here allocates device memory or synchronises; work is enqueued on the
+ * stream given to vh_ctx_create / vh_ctx_set_stream.
+ *
+ * Every call returns VH_OK (0) or a negative VH_E* code; vh_last_error() gives the
+ * message.  Arguments are validated on the host before any launch.
+ *
+ * Record / replay: between vh_plan_begin() and vh_plan_end() the op entry points
+ * append to a plan instead of launching; vh_plan_run() replays the whole recorded
+ * denoiser evaluation with no per-op host work (shapes and buffers of one
+ * denoiser call are static across the sampler's 2N-1 calls).
+ */
+#ifndef VIVID_HIP_H
+#define VIVID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_OK 0
+#define VH_EINVAL -1   /* bad argument / shape */
+#define VH_EHIP -2     /* HIP runtime error */
+#define VH_ESTATE -3   /* call not valid in the current record/replay state */
+
+typedef struct vh_ctx vh_ctx;
+typedef struct vh_plan vh_plan;
+
+int vh_abi_version(void);
+const char* vh_last_error(void);
+
+/* stream: a hipStream_t (0 = default stream). */
+int vh_ctx_create(void* stream, vh_ctx** out);
+int vh_ctx_destroy(vh_ctx* ctx);
+int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
+
+int vh_plan_begin(vh_ctx* ctx);
+int vh_plan_end(vh_ctx* ctx, vh_plan** out);
+int vh_plan_run(vh_ctx* ctx, const vh_plan* plan);
+int vh_plan_num_ops(const vh_plan* plan);
+int vh_plan_destroy(vh_plan* plan);
+
+/* ---- K1: one-time weight preparation ------------------------------------
+ * MPConv.forward's weight path, training/models.py:115-120 (normalize :37-42):
+ *   w_hat[o] = w[o] / (1e-4 + ||w[o]||_2 / sqrt(fan_in)) * gain / sqrt(fan_in)
+ * written in the layout the GEMM kernels stage from:
+ *   wt[k/4][o][k%4],  k = tap * cin_pad + ci,  tap = ky*3+kx (taps = 1 or 9),
+ * zero-filled for ci >= cin and k >= taps*cin_pad up to k_pad (multiple of 32).
+ * `gain` is read from device memory if gain_ptr != NULL (emb_gain / out_gain are
+ * 0-d Parameters, :157,:345), else gain_value is used.
+ * `dst_col0`/`dst_cols` place the block into a wider matrix (batched emb_linear). */
+typedef struct {
+    const float* w;      /* [cout][cin][taps] (PyTorch OIHW, contiguous) */
+    int cout, cin, taps;
+    int cin_pad, k_pad;
+    const float* gain_ptr;
+    float gain_value;
+    float* wt;           /* [k_pad/4][dst_cols][4] */
+    int dst_col0, dst_cols;
+} vh_prep_weight_args;
+int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* a);
+
+/* ---- K2/K3/K4 (+K5,K7,K8,K10,K12 fused): implicit-GEMM convolution --------
+ * out[m][o] = epi( sum_{tap,ci} pro( src[pixel(m)+tap][ci] ) * wt[tap*cin_pad+ci][o] )
+ * F.conv2d(x, w, padding=k//2) / x @ w.t() of MPConv.forward, :123-126, with
+ *   source  : one or two NHWC tensors read as a channel concat, each with its own
+ *             scalar weight (mp_cat :78-84, never materialised);
+ *             up=1 reads the sources at half resolution, nearest-replicated
+ *             (resample 'up' :60-61);
+ *   pro     : VH_PRO_SILU applies mp_silu (:66-67) to the concatenated input;
+ *   epi     : VH_EPI_STORE       y
+ *             VH_EPI_SCALE_SILU  mp_silu(y * cvec[row(m)][o])            (:175-176)
+ *             VH_EPI_MPSUM       clip(res[m][o]*ta + y*tb, +-clip)       (mp_sum :72-73, clip :204-205)
+ *                                res_up=1 reads res at half resolution (the block input of an 'up' block).
+ * fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate). */
+enum { VH_PRO_NONE = 0, VH_PRO_SILU = 1 };
+enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2 };
+typedef struct {
+    const float* src0; const float* src1;  /* src1 may be NULL */
+    int c0, c1;                            /* channels of each source (multiples of 4) */
+    float scale0, scale1;
+    int rows, h, w;                        /* OUTPUT geometry: rows images of h x w pixels */
+    int up;
+    int taps;                              /* 1 or 9 */
+    int pro;
+    const float* wt; int cin_pad, k_pad;   /* from vh_prep_weight */
+    int cout;
+    float* out;                            /* [rows*h*w][cout] */
+    int epi;
+    const float* cvec; int cvec_ld;        /* SCALE_SILU: cvec[row*cvec_ld + o] */
+    const float* res; int res_up;          /* MPSUM */
+    float ta, tb, clip;                    /* clip <= 0: no clipping */
+} vh_conv_args;
+int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
+
+/* ---- K6 (+K9): pixel norm with optional 2x2 mean pooling ------------------
+ * normalize(x, dim=1) :37-42 applied after resample 'down' (:58-59, a 2x2 mean):
+ *   out[p][c] = v[c] / (1e-4 + ||v||_2 / sqrt(C)),  v = x[p] or mean of the 2x2 block.
+ * rows/h/w are the OUTPUT geometry; with pool=1 the input is [rows][2h][2w][c]. */
+typedef struct {
+    const float* in; float* out;
+    int rows, h, w, c;
+    int pool;
+    int norm;     /* 0: pooling only */
+} vh_pixnorm_args;
+int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* a);
+
+/* ---- K11 part 1: q/k/v split + per-head vector norm -----------------------
+ * The view/normalize/unbind of :192-194, :279-293: the 1x1-conv output has channel
+ * index (head*D + d)*nj + j (j = q,k,v for nj=3; k,v for nj=2); each D-vector is
+ * divided by (1e-4 + ||.||_2/sqrt(D)).  q is additionally multiplied by qscale
+ * (= log2(e)/sqrt(D): SDPA's 1/sqrt(D) :198 folded with the exp2 softmax).
+ * Row `r` of `in` belongs to batch element r / rows_per_b and lands at key offset
+ * koff + (r % rows_per_b) * s  (the sequence concat of :296-297, never materialised).
+ * Q [b][head][s][D];  K,V [b][head][kl][D]. */
+typedef struct {
+    const float* in;      /* [rows][s][heads*D*nj] */
+    int rows, s, heads, d, nj;
+    int rows_per_b, koff, kl;
+    float qscale;
+    float* q; float* k; float* v;
+} vh_qkv_split_args;
+int vh_qkv_split(vh_ctx* ctx, const vh_qkv_split_args* a);
+
+/* ---- K11 part 2: attention ------------------------------------------------
+ * softmax(q k^T) v of F.scaled_dot_product_attention :198,:305 (no mask, no dropout),
+ * flash-style on fp32 MFMA; logits are in log2 units (see qscale above).
+ * n_zero_keys: that many extra keys with logit 0 and value 0 are added to the
+ * softmax denominator in closed form — the zero features of the unconditional
+ * guidance network (:727-736; normalize(0) = 0 gives k = v = 0) — without reading them.
+ * out is NHWC [b][s][heads*D] with channel = head*D + d  (:199,:308). */
+typedef struct {
+    const float* q; const float* k; const float* v;
+    int b, heads, s, kl, d;   /* d = 32 or 64 */
+    float n_zero_keys;
+    float* out;
+} vh_attention_args;
+int vh_attention(vh_ctx* ctx, const vh_attention_args* a);
+
+/* ---- K13 + K4 + K7 + K5: noise/pose embedding -----------------------------
+ * emb = mp_silu(mp_sum(emb_noise(fourier(c_noise)), emb_label(geometry), t)) :388-391,:485-488
+ * with c_noise = ln(sigma)/4 * time_scale (:638,:667).  sigma row for output row r is
+ * sigma[r*sigma_stride]; geometry row r is geometry + r*label_dim (contiguous, so the
+ * dual-source view(B,40) of :678 is label_dim=40 over the same buffer).
+ * geometry == NULL or label_dim == 0 skips the pose term.  w_* come from vh_prep_weight. */
+typedef struct {
+    const float* sigma; int sigma_stride; float time_scale;
+    const float* geometry; int label_dim; float geometry_scale;  /* 0 for uncond nets (:631) */
+    const float* freqs; const float* phases; int cnoise;
+    const float* w_noise; int w_noise_kpad;
+    const float* w_label; int w_label_kpad;
+    float label_balance;
+    int rows, cemb;
+    int raw;              /* 1: emb = emb_noise(fourier(c_noise)) only (logvar head, :687) */
+    float* emb;           /* [rows][cemb] */
+} vh_embed_args;
+int vh_embed(vh_ctx* ctx, const vh_embed_args* a);
+
+/* ---- K4 batched: every block's emb_linear in one launch -------------------
+ * cvec[r][o] = sum_k emb[r][k] * wt[k][o] + 1    (c of :175; gains folded by vh_prep_weight) */
+typedef struct {
+    const float* emb; int rows, cemb;
+    const float* wt; int k_pad; int cols;
+    float bias;
+    float* out;           /* [rows][cols] */
+} vh_linear_args;
+int vh_linear(vh_ctx* ctx, const vh_linear_args* a);
+
+/* ---- K14 + input assembly -------------------------------------------------
+ * Builds the NHWC network input: up to 4 channel segments, then a constant-ones
+ * channel (the bias channel of :394,:495,:544), zero-padded to c_pad.
+ *   kind 0: NCHW image   [*,c,h,w], source row = r*row_mul, optionally scaled by
+ *           c_in(sigma[r*row_mul]) = 1/sqrt(sigma_data^2+sigma^2)  (:637,:639)
+ *   kind 1: NHWC features [*,h,w,c], source row = r*row_mul */
+typedef struct {
+    const float* ptr; int kind; int c; int c_src; int row_mul; int scale_cin;
+} vh_segment;   /* c channels are taken from a source tensor that has c_src channels (c <= c_src) */
+typedef struct {
+    vh_segment seg[4]; int nseg;
+    const float* sigma; float sigma_data;
+    int rows, h, w, c_pad;
+    float* out;
+} vh_assemble_args;
+int vh_assemble(vh_ctx* ctx, const vh_assemble_args* a);
+
+/* D_x = c_skip * x + c_out * F_x  (:635-636,:683), NCHW out.
+ * x row for output row r is r*row_mul (dual-source: 2). F is NHWC [rows][h][w][fc], first 3 used. */
+typedef struct {
+    const float* x; int row_mul; const float* f; int fc;
+    const float* sigma; float sigma_data;
+    int rows, c, h, w;
+    float* out;
+} vh_precond_out_args;
+int vh_precond_out(vh_ctx* ctx, const vh_precond_out_args* a);
+
+/* ---- K13 + K15: depth-warp Fourier features (config 5) --------------------
+ * get_warped_features training/utils.py:204-216 (warp_image :189-201, decompose_geometry
+ * :84-94): pixel centres are un-projected with the source depth, moved by the inverse
+ * of tgt2src, projected with K_tgt, divided (NaN -> 0); both grids are Fourier-embedded
+ * with the first 64 features of logvar_fourier (:96-101) per coordinate.
+ * geometry is the normalised 20-vector; mean/std are the per-image-size statistics
+ * (vivid_amd/geometry.py).  Outputs are NHWC [rows][s][s][128]. */
+typedef struct {
+    const float* depth;     /* NCHW src with depth in channel `depth_ch` of `src_c` channels */
+    int src_c, depth_ch;
+    const float* geometry;  /* [rows][20] */
+    float mean[20]; float std[20];
+    const float* freqs; const float* phases;
+    int rows, s;
+    float* grid_feat; float* warp_feat;
+} vh_warp_args;
+int vh_warp_features(vh_ctx* ctx, const vh_warp_args* a);
+
+/* ---- K16: sampler update (generate_images.py:93-94,108-109) ---------------
+ * d = (x - D)/t_hat;  Euler: x_next = x + (t_next - t_hat) * d           (d_out written)
+ * Heun : x_next = x + (t_next - t_hat) * (0.5*d_prev + 0.5*(x_probe - D)/t_next)
+ * with classifier-free guidance folded in: D = ref.lerp(D_cond, guidance) (:62) when d_ref != NULL.
+ * x rows are read at row*row_mul (dual-source row pairs) and x_next is written to every
+ * row of the pair (:96-98,110-111). */
+typedef struct {
+    const float* x_hat; const float* x_probe;   /* x_probe NULL: Euler step */
+    const float* d_cond; const float* d_ref; float guidance;
+    float* d_cur;          /* Euler: written; Heun: read */
+    float t_hat, t_next;
+    int rows, row_mul; size_t row_elems;
+    float* x_next;
+} vh_sampler_step_args;
+int vh_sampler_step(vh_ctx* ctx, const vh_sampler_step_args* a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIVID_HIP_H */

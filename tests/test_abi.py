@@ -1,0 +1,62 @@
+"""CPU: the C-ABI library loads and exports every symbol include/vivid_hip.h declares,
+and the ctypes mirrors have the sizes the header implies (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from vivid_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header():
+    return open(os.path.join(ROOT, "include", "vivid_hip.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(vh_\w+)\s*\(", _header(), flags=re.M))
+    assert declared, "no declarations found in the header"
+    assert declared == set(_lib.OPS) | set(_lib.CONTROL)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.vh_abi_version() == 1
+
+
+def test_struct_mirrors_match_header_field_counts():
+    h = _header()
+    pairs = {"vh_prep_weight_args": _lib.PrepWeightArgs, "vh_conv_args": _lib.ConvArgs, "vh_pixnorm_args": _lib.PixnormArgs,
+             "vh_qkv_split_args": _lib.QkvSplitArgs, "vh_attention_args": _lib.AttentionArgs, "vh_embed_args": _lib.EmbedArgs,
+             "vh_linear_args": _lib.LinearArgs, "vh_segment": _lib.Segment, "vh_assemble_args": _lib.AssembleArgs,
+             "vh_precond_out_args": _lib.PrecondOutArgs, "vh_warp_args": _lib.WarpArgs,
+             "vh_sampler_step_args": _lib.SamplerStepArgs}
+    for cname, st in pairs.items():
+        m = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + r"\s*;", h, flags=re.S)
+        assert m, cname
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        n = 0
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            n += decl.count(",") + 1
+        assert n == len(st._fields_), (cname, n, len(st._fields_))
+
+
+def test_argument_validation_without_gpu():
+    """Host-side validation rejects bad shapes before any launch (safe without a GPU)."""
+    L = _lib.lib()
+    ctx = _lib.Context(0)
+    a = _lib.ConvArgs(taps=5)
+    with pytest.raises(_lib.VividHipError, match="taps"):
+        ctx.call("vh_conv", a)
+    a = _lib.AttentionArgs(q=16, k=16, v=16, out=16, b=1, heads=1, s=4, kl=4, d=96)
+    with pytest.raises(_lib.VividHipError, match="head dim"):
+        ctx.call("vh_attention", a)
+    ctx.plan_begin()
+    with pytest.raises(_lib.VividHipError):
+        ctx.plan_begin()
+    plan = ctx.plan_end()
+    assert plan.num_ops == 0

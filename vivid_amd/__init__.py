@@ -1,0 +1,13 @@
+"""vivid_amd — MI355X-native (gfx950) denoiser for VIVID novel-view synthesis.
+
+Drop-in for the reference's hot path: ``NVPrecond`` (training/models.py) and
+``edm_sampler`` (generate_images.py), computed by hand-written HIP kernels in
+``libvivid_hip.so``.  See DESIGN.md.
+"""
+from .arch import NetConfig, vivid_base, vivid_sr, vivid_uncond  # noqa: F401
+from .net import NVPrecond  # noqa: F401
+from .sampler import StackedRandomGenerator, edm_sampler  # noqa: F401
+from .weights import synth_state_dict  # noqa: F401
+
+__all__ = ["NVPrecond", "edm_sampler", "StackedRandomGenerator", "NetConfig", "vivid_base", "vivid_sr",
+           "vivid_uncond", "synth_state_dict"]

@@ -1,0 +1,199 @@
+"""ctypes binding of libvivid_hip.so (the C ABI in include/vivid_hip.h).
+
+The structures below mirror the header field for field.  There is no CPU
+fallback: if the shared library is missing, :func:`lib` raises with the build
+command, and every op raises :class:`VividHipError` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvivid_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class VividHipError(RuntimeError):
+    pass
+
+
+class PrepWeightArgs(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("cout", C.c_int), ("cin", C.c_int), ("taps", C.c_int),
+                ("cin_pad", C.c_int), ("k_pad", C.c_int), ("gain_ptr", C.c_void_p),
+                ("gain_value", C.c_float), ("wt", C.c_void_p), ("dst_col0", C.c_int), ("dst_cols", C.c_int)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+                ("scale0", C.c_float), ("scale1", C.c_float),
+                ("rows", C.c_int), ("h", C.c_int), ("w", C.c_int), ("up", C.c_int), ("taps", C.c_int),
+                ("pro", C.c_int), ("wt", C.c_void_p), ("cin_pad", C.c_int), ("k_pad", C.c_int),
+                ("cout", C.c_int), ("out", C.c_void_p), ("epi", C.c_int),
+                ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
+                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float)]
+
+
+class PixnormArgs(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("h", C.c_int),
+                ("w", C.c_int), ("c", C.c_int), ("pool", C.c_int), ("norm", C.c_int)]
+
+
+class QkvSplitArgs(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("rows", C.c_int), ("s", C.c_int), ("heads", C.c_int),
+                ("d", C.c_int), ("nj", C.c_int), ("rows_per_b", C.c_int), ("koff", C.c_int),
+                ("kl", C.c_int), ("qscale", C.c_float), ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p)]
+
+
+class AttentionArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("b", C.c_int),
+                ("heads", C.c_int), ("s", C.c_int), ("kl", C.c_int), ("d", C.c_int),
+                ("n_zero_keys", C.c_float), ("out", C.c_void_p)]
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("sigma", C.c_void_p), ("sigma_stride", C.c_int), ("time_scale", C.c_float),
+                ("geometry", C.c_void_p), ("label_dim", C.c_int), ("geometry_scale", C.c_float),
+                ("freqs", C.c_void_p), ("phases", C.c_void_p), ("cnoise", C.c_int),
+                ("w_noise", C.c_void_p), ("w_noise_kpad", C.c_int),
+                ("w_label", C.c_void_p), ("w_label_kpad", C.c_int),
+                ("label_balance", C.c_float), ("rows", C.c_int), ("cemb", C.c_int), ("raw", C.c_int),
+                ("emb", C.c_void_p)]
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("rows", C.c_int), ("cemb", C.c_int), ("wt", C.c_void_p),
+                ("k_pad", C.c_int), ("cols", C.c_int), ("bias", C.c_float), ("out", C.c_void_p)]
+
+
+class Segment(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("kind", C.c_int), ("c", C.c_int), ("c_src", C.c_int),
+                ("row_mul", C.c_int), ("scale_cin", C.c_int)]
+
+
+class AssembleArgs(C.Structure):
+    _fields_ = [("seg", Segment * 4), ("nseg", C.c_int), ("sigma", C.c_void_p), ("sigma_data", C.c_float),
+                ("rows", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c_pad", C.c_int), ("out", C.c_void_p)]
+
+
+class PrecondOutArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("row_mul", C.c_int), ("f", C.c_void_p), ("fc", C.c_int),
+                ("sigma", C.c_void_p), ("sigma_data", C.c_float), ("rows", C.c_int), ("c", C.c_int),
+                ("h", C.c_int), ("w", C.c_int), ("out", C.c_void_p)]
+
+
+class WarpArgs(C.Structure):
+    _fields_ = [("depth", C.c_void_p), ("src_c", C.c_int), ("depth_ch", C.c_int), ("geometry", C.c_void_p),
+                ("mean", C.c_float * 20), ("std", C.c_float * 20), ("freqs", C.c_void_p), ("phases", C.c_void_p),
+                ("rows", C.c_int), ("s", C.c_int), ("grid_feat", C.c_void_p), ("warp_feat", C.c_void_p)]
+
+
+class SamplerStepArgs(C.Structure):
+    _fields_ = [("x_hat", C.c_void_p), ("x_probe", C.c_void_p), ("d_cond", C.c_void_p), ("d_ref", C.c_void_p),
+                ("guidance", C.c_float), ("d_cur", C.c_void_p), ("t_hat", C.c_float), ("t_next", C.c_float),
+                ("rows", C.c_int), ("row_mul", C.c_int), ("row_elems", C.c_size_t), ("x_next", C.c_void_p)]
+
+
+# every symbol include/vivid_hip.h declares: name -> (args struct or None)
+OPS = {
+    "vh_prep_weight": PrepWeightArgs, "vh_conv": ConvArgs, "vh_pixnorm": PixnormArgs,
+    "vh_qkv_split": QkvSplitArgs, "vh_attention": AttentionArgs, "vh_embed": EmbedArgs,
+    "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
+    "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs,
+}
+CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",
+           "vh_plan_begin", "vh_plan_end", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
+
+_lib = None
+
+
+def lib():
+    """Load libvivid_hip.so (once).  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VividHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C vivid_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.vh_abi_version.restype = C.c_int
+    L.vh_last_error.restype = C.c_char_p
+    L.vh_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.vh_ctx_destroy.argtypes = [C.c_void_p]
+    L.vh_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.vh_plan_begin.argtypes = [C.c_void_p]
+    L.vh_plan_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.vh_plan_run.argtypes = [C.c_void_p, C.c_void_p]
+    L.vh_plan_num_ops.argtypes = [C.c_void_p]
+    L.vh_plan_destroy.argtypes = [C.c_void_p]
+    for name, st in OPS.items():
+        fn = getattr(L, name)
+        fn.argtypes = [C.c_void_p, C.POINTER(st)]
+        fn.restype = C.c_int
+    for name in CONTROL:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().vh_last_error()
+        raise VividHipError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+class Context:
+    """A vh_ctx bound to a HIP stream."""
+
+    def __init__(self, stream_handle: int = 0):
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.vh_ctx_create(C.c_void_p(stream_handle), C.byref(h)), "vh_ctx_create")
+        self.handle = h
+
+    def set_stream(self, stream_handle: int):
+        check(self._L.vh_ctx_set_stream(self.handle, C.c_void_p(stream_handle)), "vh_ctx_set_stream")
+
+    def call(self, name: str, args):
+        check(getattr(self._L, name)(self.handle, C.byref(args)), name)
+
+    def plan_begin(self):
+        check(self._L.vh_plan_begin(self.handle), "vh_plan_begin")
+
+    def plan_end(self) -> "Plan":
+        p = C.c_void_p()
+        check(self._L.vh_plan_end(self.handle, C.byref(p)), "vh_plan_end")
+        return Plan(self, p)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._L.vh_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    def __init__(self, ctx: Context, handle):
+        self.ctx, self.handle = ctx, handle
+
+    @property
+    def num_ops(self) -> int:
+        return self.ctx._L.vh_plan_num_ops(self.handle)
+
+    def run(self):
+        check(self.ctx._L.vh_plan_run(self.ctx.handle, self.handle), "vh_plan_run")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.ctx._L.vh_plan_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

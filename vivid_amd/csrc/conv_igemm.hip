@@ -1,0 +1,251 @@
+// Implicit-GEMM convolution / pointwise GEMM on fp32 MFMA for gfx950 (CDNA4).
+//
+// Replaces the F.conv2d / x @ w.t() call sites of MPConv.forward (reference
+// training/models.py:123-126) together with the element-wise ops the reference runs
+// around them: mp_silu on the input (:66-67, :174), the two-tensor mp_cat (:78-84,
+// :403/:509/:563), nearest 2x upsampling (:60-61), the embedding scale + mp_silu on the
+// output (:175-176), and mp_sum + clip with the residual (:72-73, :184, :204-205).
+//
+// GEMM view: M = rows*h*w output pixels, N = cout, K = taps*cin_pad.
+//   A[m][k] is gathered from NHWC activations (k = tap*cin_pad + ci), B[k][n] are the
+//   prepared weights wt[k/4][n][k%4].
+// Tile: 128(M) x 128(N) x 32(K) per 256-thread workgroup; 4 waves as 2x2, each wave
+//   64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles (exact fp32 products, fp32 accumulate).
+// LDS: operands are stored as float4 = 4 consecutive k for one m (or n):
+//   sA[k4][m ^ k4], sB[k4][n].  Lane l of a wave reads the float4 of k-group
+//   k4 = 2*kg + (l>>5); its 4 components feed 4 successive MFMAs, so within one MFMA the
+//   two lane halves supply k = 8kg+j and 8kg+4+j — a permutation of k that A and B share.
+//   The XOR keeps the 8 staging lanes that hold the same pixel (different k4) on different
+//   16-byte slots (ds_write_b128 is serviced 8 lanes at a time); reads stay conflict-free.
+// Pipeline: global -> registers for tile t+1 is issued before the MFMAs of tile t, written
+//   to the other LDS buffer after them; one barrier per K-tile.
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32, K4 = BK / 4;
+
+struct ConvK {
+    const float* src0; const float* src1;
+    int c0, c1; float scale0, scale1;
+    int h, w, up, pro;
+    const float4* wt; int cin_pad, k_pad, cout;
+    float* out; int epi;
+    const float* cvec; int cvec_ld;
+    const float* res; int res_up;
+    float ta, tb, clip;
+    int M, HW, NT;
+};
+
+__device__ __forceinline__ float mp_silu_dev(float v) {
+    // silu(v)/0.596 = v / (1 + exp(-v)) / 0.596
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * v);
+    return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
+    __shared__ float4 sA[2][K4 * BM];
+    __shared__ float4 sB[2][K4 * BN];
+
+    const int t = threadIdx.x;
+    const int nt = blockIdx.x % a.NT, mt = blockIdx.x / a.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- staging maps -----------------------------------------------------
+    const int k4a = t & 7, ma = t >> 3;          // A: 8 k-groups x 32 pixels, 4 passes
+    const int Hs = a.up ? (a.h >> 1) : a.h, Ws = a.up ? (a.w >> 1) : a.w;
+    int py[4], px[4], pbase[4];
+    bool pv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ma + 32 * i;
+        pv[i] = gm < a.M;
+        const int g = pv[i] ? gm : 0;
+        const int img = g / a.HW;
+        const int rem = g - img * a.HW;
+        py[i] = rem / a.w;
+        px[i] = rem - py[i] * a.w;
+        pbase[i] = img * Hs * Ws;
+    }
+    const int nb = t & 127, k4b = t >> 7;        // B: 128 columns x 2 k-groups, 4 passes
+    const bool nvalid = (n0 + nb) < a.cout;
+    const float4* wptr = a.wt + (size_t)k4b * a.cout + (nvalid ? (n0 + nb) : 0);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    float rsc = 1.f;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK + k4a * 4;
+        const int tap = (TAPS == 1) ? (k0 >= a.cin_pad ? 1 : 0) : k0 / a.cin_pad;
+        const int ci = k0 - tap * a.cin_pad;
+        int dy = 0, dx = 0;
+        if (TAPS == 9) {
+            const int ty = tap / 3;
+            dy = ty - 1;
+            dx = tap - ty * 3 - 1;
+        }
+        const float* sp;
+        int cs, cc;
+        bool chok = tap < TAPS;
+        if (ci < a.c0) {
+            sp = a.src0; cs = a.c0; cc = ci; rsc = a.scale0;
+        } else {
+            sp = a.src1; cs = a.c1; cc = ci - a.c0; rsc = a.scale1;
+            chok = chok && (sp != nullptr) && (cc < a.c1);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = py[i] + dy, xx = px[i] + dx;
+            const bool ok = pv[i] && chok && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+            const size_t pix = (size_t)(pbase[i] + (yy >> a.up) * Ws + (xx >> a.up));
+            ra[i] = ok ? *reinterpret_cast<const float4*>(sp + pix * cs + cc) : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rb[i] = nvalid ? wptr[(size_t)(kt * K4 + 2 * i) * a.cout] : zero4;
+    };
+
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 v = ra[i];
+            v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+            if (a.pro == VH_PRO_SILU) {
+                v.x = mp_silu_dev(v.x); v.y = mp_silu_dev(v.y);
+                v.z = mp_silu_dev(v.z); v.w = mp_silu_dev(v.w);
+            }
+            sA[buf][k4a * BM + ((ma + 32 * i) ^ k4a)] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sB[buf][(k4b + 2 * i) * BN + nb] = rb[i];
+    };
+
+    const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
+    const int wm = wv >> 1, wn = wv & 1;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            const int k4 = kg * 2 + hh;
+            float4 af[2], bf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) af[mi] = sA[buf][k4 * BM + ((wm * 64 + mi * 32 + lr) ^ k4)];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) bf[ni] = sB[buf][k4 * BN + wn * 64 + ni * 32 + lr];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const float av = j == 0 ? af[mi].x : j == 1 ? af[mi].y : j == 2 ? af[mi].z : af[mi].w;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const float bv = j == 0 ? bf[ni].x : j == 1 ? bf[ni].y : j == 2 ? bf[ni].z : bf[ni].w;
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- main loop ----------------------------------------------------------
+    const int KT = a.k_pad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        compute(buf);
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------
+    // C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    const int Hr = a.h >> 1, Wr = a.w >> 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (gm >= a.M) continue;
+            int img = 0;
+            size_t rrow = (size_t)gm;
+            if (a.epi == VH_EPI_SCALE_SILU || (a.epi == VH_EPI_MPSUM && a.res_up)) {
+                img = gm / a.HW;
+                if (a.epi == VH_EPI_MPSUM) {
+                    const int rem = gm - img * a.HW;
+                    const int y = rem / a.w, x = rem - y * a.w;
+                    rrow = (size_t)((img * Hr + (y >> 1)) * Wr + (x >> 1));
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int gn = n0 + wn * 64 + ni * 32 + lr;
+                if (gn >= a.cout) continue;
+                float y = acc[mi][ni][r];
+                if (a.epi == VH_EPI_SCALE_SILU) {
+                    y = mp_silu_dev(y * a.cvec[(size_t)img * a.cvec_ld + gn]);
+                } else if (a.epi == VH_EPI_MPSUM) {
+                    y = a.res[rrow * a.cout + gn] * a.ta + y * a.tb;
+                    if (a.clip > 0.f) y = fminf(fmaxf(y, -a.clip), a.clip);
+                }
+                a.out[(size_t)gm * a.cout + gn] = y;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_conv: null args");
+    const vh_conv_args a = *p;
+    VH_REQUIRE(a.taps == 1 || a.taps == 9, "vh_conv: taps must be 1 or 9 (got %d)", a.taps);
+    VH_REQUIRE(a.src0 && a.wt && a.out, "vh_conv: null tensor");
+    VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.cout > 0, "vh_conv: bad geometry");
+    VH_REQUIRE(a.c0 > 0 && a.c0 % 4 == 0, "vh_conv: c0 must be a positive multiple of 4 (got %d)", a.c0);
+    VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 4 == 0) : a.c1 == 0, "vh_conv: bad c1 %d", a.c1);
+    VH_REQUIRE(a.cin_pad % 4 == 0 && a.cin_pad >= a.c0 + a.c1, "vh_conv: cin_pad %d < c0+c1 %d or not /4", a.cin_pad, a.c0 + a.c1);
+    VH_REQUIRE(a.k_pad % BK == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_conv: k_pad %d invalid for taps*cin_pad %d", a.k_pad, a.taps * a.cin_pad);
+    VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.wt), "vh_conv: source/weight pointers must be 16-byte aligned");
+    VH_REQUIRE(!a.up || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: up needs even output size");
+    VH_REQUIRE(a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU, "vh_conv: bad prologue");
+    VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_MPSUM, "vh_conv: bad epilogue");
+    VH_REQUIRE(a.epi != VH_EPI_SCALE_SILU || (a.cvec && a.cvec_ld >= a.cout), "vh_conv: SCALE_SILU needs cvec with ld >= cout");
+    VH_REQUIRE(a.epi != VH_EPI_MPSUM || a.res, "vh_conv: MPSUM needs res");
+    VH_REQUIRE(!(a.epi == VH_EPI_MPSUM && a.res_up) || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: res_up needs even output size");
+    const long long M = (long long)a.rows * a.h * a.w;
+    VH_REQUIRE(M < (1LL << 31) - BM, "vh_conv: too many pixels");
+    const long long MT = (M + BM - 1) / BM, NT = (a.cout + BN - 1) / BN;
+    VH_REQUIRE(MT * NT < (1LL << 31), "vh_conv: grid too large");
+
+    ConvK k;
+    k.src0 = a.src0; k.src1 = a.src1; k.c0 = a.c0; k.c1 = a.c1; k.scale0 = a.scale0; k.scale1 = a.scale1;
+    k.h = a.h; k.w = a.w; k.up = a.up ? 1 : 0; k.pro = a.pro;
+    k.wt = reinterpret_cast<const float4*>(a.wt); k.cin_pad = a.cin_pad; k.k_pad = a.k_pad; k.cout = a.cout;
+    k.out = a.out; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;
+    k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
+    k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
+    const int taps = a.taps;
+    const unsigned grid = (unsigned)(MT * NT);
+    return vh_dispatch(ctx, [k, taps, grid](hipStream_t s) -> int {
+        if (taps == 9)
+            hipLaunchKernelGGL(conv_igemm_f32<9>, dim3(grid), dim3(256), 0, s, k);
+        else
+            hipLaunchKernelGGL(conv_igemm_f32<1>, dim3(grid), dim3(256), 0, s, k);
+        return vh_check_launch("conv_igemm_f32");
+    });
+}

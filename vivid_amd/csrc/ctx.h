@@ -1,0 +1,56 @@
+// Shared host-side plumbing for libvivid_hip.so: context, record/replay plan, error reporting.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/vivid_hip.h"
+
+struct vh_plan {
+    std::vector<std::function<int(hipStream_t)>> ops;
+};
+
+struct vh_ctx {
+    hipStream_t stream = nullptr;
+    bool recording = false;
+    vh_plan* cur = nullptr;
+};
+
+std::string& vh_err();
+
+inline int vh_fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    vh_err() = buf;
+    return code;
+}
+
+#define VH_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return vh_fail(VH_EINVAL, __VA_ARGS__);    \
+    } while (0)
+
+inline int vh_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vh_fail(VH_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return VH_OK;
+}
+
+// Launch now, or append to the plan being recorded.
+template <class F>
+inline int vh_dispatch(vh_ctx* ctx, F&& launch) {
+    if (!ctx) return vh_fail(VH_EINVAL, "null context");
+    if (ctx->recording) {
+        ctx->cur->ops.emplace_back(std::forward<F>(launch));
+        return VH_OK;
+    }
+    return launch(ctx->stream);
+}
+
+inline bool vh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

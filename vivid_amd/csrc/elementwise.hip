@@ -1,0 +1,426 @@
+// HBM-bound helper kernels of the VIVID denoiser for gfx950: weight preparation, pixel norm
+// (+2x2 mean pooling), q/k/v split + head norm, noise/pose embedding, batched emb_linear,
+// input assembly, preconditioned output, depth-warp Fourier features, sampler update.
+// Reference lines are cited at each entry point in include/vivid_hip.h.
+#include "ctx.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+    v = wave_sum(v);
+    const int t = threadIdx.x;
+    if ((t & 63) == 0) red[t >> 6] = v;
+    __syncthreads();
+    const float r = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ float mp_silu_dev(float v) {
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * v);
+    return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
+}
+
+// ---------------------------------------------------------------- weight prep
+__global__ __launch_bounds__(256) void prep_weight_k(vh_prep_weight_args a) {
+    __shared__ float red[4];
+    const int o = blockIdx.x, t = threadIdx.x;
+    const int fan = a.cin * a.taps;
+    const float* w = a.w + (size_t)o * fan;
+    float ss = 0.f;
+    for (int i = t; i < fan; i += 256) ss += w[i] * w[i];
+    ss = block_sum_256(ss, red);
+    const float gain = a.gain_ptr ? *a.gain_ptr : a.gain_value;
+    const float rs = rsqrtf((float)fan);
+    const float scale = gain * rs / (1e-4f + sqrtf(ss) * rs);
+    for (int k = t; k < a.k_pad; k += 256) {
+        const int tap = k / a.cin_pad, ci = k - tap * a.cin_pad;
+        float v = 0.f;
+        if (tap < a.taps && ci < a.cin) v = w[ci * a.taps + tap] * scale;
+        a.wt[((size_t)(k >> 2) * a.dst_cols + a.dst_col0 + o) * 4 + (k & 3)] = v;
+    }
+}
+
+// ---------------------------------------------------------------- pixel norm (+pool)
+// one wave per output pixel; channels in float4
+__global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long npix) {
+    const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= npix) return;
+    const int lane = threadIdx.x & 63;
+    const int c4 = a.c >> 2;
+    const float4* src[4];
+    int nsrc = 1;
+    if (a.pool) {
+        const int hw = a.h * a.w;
+        const int img = (int)(p / hw), rem = (int)(p - (long long)img * hw);
+        const int y = rem / a.w, x = rem - y * a.w;
+        const int wi = 2 * a.w;
+        const size_t base = ((size_t)img * 2 * a.h + 2 * y) * wi + 2 * x;
+        src[0] = reinterpret_cast<const float4*>(a.in + base * a.c);
+        src[1] = reinterpret_cast<const float4*>(a.in + (base + 1) * a.c);
+        src[2] = reinterpret_cast<const float4*>(a.in + (base + wi) * a.c);
+        src[3] = reinterpret_cast<const float4*>(a.in + (base + wi + 1) * a.c);
+        nsrc = 4;
+    } else {
+        src[0] = reinterpret_cast<const float4*>(a.in + (size_t)p * a.c);
+        src[1] = src[2] = src[3] = src[0];
+    }
+    float4* dst = reinterpret_cast<float4*>(a.out + (size_t)p * a.c);
+    auto fetch = [&](int i) {
+        float4 v = src[0][i];
+        if (nsrc == 4) {
+            const float4 b = src[1][i], c = src[2][i], d = src[3][i];
+            v.x = 0.25f * (v.x + b.x + c.x + d.x); v.y = 0.25f * (v.y + b.y + c.y + d.y);
+            v.z = 0.25f * (v.z + b.z + c.z + d.z); v.w = 0.25f * (v.w + b.w + c.w + d.w);
+        }
+        return v;
+    };
+    float scale = 1.f;
+    if (a.norm) {
+        float ss = 0.f;
+        for (int i = lane; i < c4; i += 64) {
+            const float4 v = fetch(i);
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        ss = wave_sum(ss);
+        scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
+    }
+    for (int i = lane; i < c4; i += 64) {
+        float4 v = fetch(i);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        dst[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- q/k/v split + head norm
+// a group of D lanes handles one (row, s, head)
+template <int D>
+__global__ __launch_bounds__(256) void qkv_split_k(vh_qkv_split_args a, long long ngroups) {
+    constexpr int GPB = 256 / D;
+    const long long gid = (long long)blockIdx.x * GPB + threadIdx.x / D;
+    if (gid >= ngroups) return;     // D divides 64: a whole shuffle group exits together
+    const int d = threadIdx.x % D;
+    const int head = (int)(gid % a.heads);
+    const long long pix = gid / a.heads;
+    const int s = (int)(pix % a.s), row = (int)(pix / a.s);
+    const int bb = row / a.rows_per_b, seg = row - bb * a.rows_per_b;
+    const float* in = a.in + ((size_t)pix * a.heads * D + (size_t)head * D + d) * a.nj;
+    const float rsd = rsqrtf((float)D);
+    for (int j = 0; j < a.nj; ++j) {
+        const float v = in[j];
+        float ss = v * v;
+#pragma unroll
+        for (int o = D / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+        float y = v / (1e-4f + sqrtf(ss) * rsd);
+        const bool is_q = (a.nj == 3 && j == 0);
+        if (is_q) {
+            a.q[(((size_t)bb * a.heads + head) * a.s + s) * D + d] = y * a.qscale;
+        } else {
+            float* dst = ((a.nj == 3) ? (j == 1) : (j == 0)) ? a.k : a.v;
+            dst[(((size_t)bb * a.heads + head) * a.kl + a.koff + seg * a.s + s) * D + d] = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- embedding
+__global__ __launch_bounds__(256) void embed_k(vh_embed_args a) {
+    __shared__ float sf[1024];
+    __shared__ float sg[64];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const float sigma = a.sigma[(size_t)r * a.sigma_stride];
+    const float cn = (logf(sigma) * 0.25f) * a.time_scale;
+    for (int i = t; i < a.cnoise; i += 256) {
+        const float ph = __fadd_rn(__fmul_rn(cn, a.freqs[i]), a.phases[i]);
+        sf[i] = cosf(ph) * 1.41421356237309515f;
+    }
+    const bool lab = !a.raw && a.geometry && a.label_dim > 0;
+    if (lab)
+        for (int i = t; i < a.label_dim; i += 256) sg[i] = a.geometry[(size_t)r * a.label_dim + i] * a.geometry_scale;
+    __syncthreads();
+    const float tb = a.label_balance;
+    const float inv = rsqrtf((1.f - tb) * (1.f - tb) + tb * tb);
+    for (int co = t; co < a.cemb; co += 256) {
+        float e1 = 0.f;
+        for (int k = 0; k < a.cnoise; ++k) e1 += sf[k] * a.w_noise[((size_t)(k >> 2) * a.cemb + co) * 4 + (k & 3)];
+        float e = e1;
+        if (lab) {
+            float e2 = 0.f;
+            for (int k = 0; k < a.label_dim; ++k) e2 += sg[k] * a.w_label[((size_t)(k >> 2) * a.cemb + co) * 4 + (k & 3)];
+            e = (e1 + tb * (e2 - e1)) * inv;
+        }
+        a.emb[(size_t)r * a.cemb + co] = a.raw ? e : mp_silu_dev(e);
+    }
+}
+
+// ---------------------------------------------------------------- small batched linear
+__global__ __launch_bounds__(256) void linear_k(vh_linear_args a) {
+    __shared__ float se[1024];
+    const int r = blockIdx.y, t = threadIdx.x;
+    for (int i = t; i < a.cemb; i += 256) se[i] = a.emb[(size_t)r * a.cemb + i];
+    __syncthreads();
+    const int o = blockIdx.x * 256 + t;
+    if (o >= a.cols) return;
+    const float4* w = reinterpret_cast<const float4*>(a.wt);
+    float acc = 0.f;
+    for (int k4 = 0; k4 < (a.cemb >> 2); ++k4) {
+        const float4 wv = w[(size_t)k4 * a.cols + o];
+        acc += se[4 * k4] * wv.x + se[4 * k4 + 1] * wv.y + se[4 * k4 + 2] * wv.z + se[4 * k4 + 3] * wv.w;
+    }
+    a.out[(size_t)r * a.cols + o] = acc + a.bias;
+}
+
+// ---------------------------------------------------------------- input assembly
+__global__ __launch_bounds__(256) void assemble_k(vh_assemble_args a, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % a.c_pad);
+    const long long pix = i / a.c_pad;
+    const int hw = a.h * a.w;
+    const int r = (int)(pix / hw), p = (int)(pix - (long long)r * hw);
+    float v = 0.f;
+    int c0 = 0;
+    bool done = false;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < a.nseg && !done) {
+            const vh_segment sg = a.seg[s];
+            if (c < c0 + sg.c) {
+                const int cc = c - c0;
+                const size_t sr = (size_t)r * sg.row_mul;
+                v = sg.kind == 0 ? sg.ptr[(sr * sg.c_src + cc) * hw + p] : sg.ptr[(sr * hw + p) * sg.c_src + cc];
+                if (sg.scale_cin) {
+                    const float sig = a.sigma[sr];
+                    v *= 1.0f / sqrtf(a.sigma_data * a.sigma_data + sig * sig);
+                }
+                done = true;
+            }
+            c0 += sg.c;
+        }
+    }
+    if (!done && c == c0) v = 1.f;      // the constant-ones (bias) channel
+    a.out[i] = v;
+}
+
+// ---------------------------------------------------------------- preconditioned output
+__global__ __launch_bounds__(256) void precond_out_k(vh_precond_out_args a, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int hw = a.h * a.w;
+    const int p = (int)(i % hw);
+    const long long rc = i / hw;
+    const int c = (int)(rc % a.c), r = (int)(rc / a.c);
+    const size_t sr = (size_t)r * a.row_mul;
+    const float sig = a.sigma[sr];
+    const float sd = a.sigma_data;
+    const float den = sig * sig + sd * sd;
+    const float c_skip = sd * sd / den;
+    const float c_out = sig * sd / sqrtf(den);
+    const float x = a.x[(sr * a.c + c) * hw + p];
+    const float f = a.f[((size_t)r * hw + p) * a.fc + c];
+    a.out[i] = c_skip * x + c_out * f;
+}
+
+// ---------------------------------------------------------------- depth-warp Fourier features
+// thread per (row, pixel, channel 0..127): channel = 64*axis + k
+__global__ __launch_bounds__(256) void warp_features_k(vh_warp_args a, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ch = (int)(i & 127);
+    const long long pix = i >> 7;
+    const int ss = a.s * a.s;
+    const int r = (int)(pix / ss), p = (int)(pix - (long long)r * ss);
+    const int yi = p / a.s, xi = p - yi * a.s;
+    const int axis = ch >> 6, kf = ch & 63;
+    const float g0 = yi + 0.5f, g1 = xi + 0.5f;     // meshgrid 'ij': coordinate 0 = row index
+    float g[20];
+#pragma unroll
+    for (int j = 0; j < 20; ++j) g[j] = a.geometry[(size_t)r * 20 + j] * a.std[j] + a.mean[j];
+    // unproject with K_src: K^-1 [g0, g1, 1]
+    const float depth = a.depth[((size_t)r * a.src_c + a.depth_ch) * ss + p];
+    const float X = (g0 - g[14]) / g[12] * depth, Y = (g1 - g[15]) / g[13] * depth, Z = depth;
+    // inverse of [R t; 0 1]: R^-1 (w - t)
+    const float r00 = g[0], r01 = g[1], r02 = g[2], t0 = g[3];
+    const float r10 = g[4], r11 = g[5], r12 = g[6], t1 = g[7];
+    const float r20 = g[8], r21 = g[9], r22 = g[10], t2 = g[11];
+    const float c00 = r11 * r22 - r12 * r21, c01 = r02 * r21 - r01 * r22, c02 = r01 * r12 - r02 * r11;
+    const float c10 = r12 * r20 - r10 * r22, c11 = r00 * r22 - r02 * r20, c12 = r02 * r10 - r00 * r12;
+    const float c20 = r10 * r21 - r11 * r20, c21 = r01 * r20 - r00 * r21, c22 = r00 * r11 - r01 * r10;
+    const float idet = 1.0f / (r00 * c00 + r01 * c10 + r02 * c20);
+    const float dx = X - t0, dy = Y - t1, dz = Z - t2;
+    const float wx = (c00 * dx + c01 * dy + c02 * dz) * idet;
+    const float wy = (c10 * dx + c11 * dy + c12 * dz) * idet;
+    const float wz = (c20 * dx + c21 * dy + c22 * dz) * idet;
+    // project with K_tgt and divide
+    float u = (g[16] * wx + g[18] * wz) / wz;
+    float v = (g[17] * wy + g[19] * wz) / wz;
+    if (u != u) u = 0.f;
+    if (v != v) v = 0.f;
+    const float f = a.freqs[kf], ph = a.phases[kf];
+    const float cg = axis == 0 ? g0 : g1;
+    const float cw = axis == 0 ? u : v;
+    a.grid_feat[i] = cosf(__fadd_rn(__fmul_rn(cg, f), ph)) * 1.41421356237309515f;
+    a.warp_feat[i] = cosf(__fadd_rn(__fmul_rn(cw, f), ph)) * 1.41421356237309515f;
+}
+
+// ---------------------------------------------------------------- sampler update
+__global__ __launch_bounds__(256) void sampler_step_k(vh_sampler_step_args a, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long long r = i / (long long)a.row_elems, e = i - r * (long long)a.row_elems;
+    const size_t xi = (size_t)r * a.row_mul * a.row_elems + e;
+    float D = a.d_cond[i];
+    if (a.d_ref) {
+        const float ref = a.d_ref[i];
+        D = ref + a.guidance * (D - ref);
+    }
+    const float xh = a.x_hat[xi];
+    float xn;
+    if (!a.x_probe) {
+        const float d = (xh - D) / a.t_hat;
+        a.d_cur[i] = d;
+        xn = xh + (a.t_next - a.t_hat) * d;
+    } else {
+        const float dp = (a.x_probe[xi] - D) / a.t_next;
+        xn = xh + (a.t_next - a.t_hat) * (0.5f * a.d_cur[i] + 0.5f * dp);
+    }
+    for (int j = 0; j < a.row_mul; ++j) a.x_next[xi + (size_t)j * a.row_elems] = xn;
+}
+
+inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_prep_weight: null args");
+    const vh_prep_weight_args a = *p;
+    VH_REQUIRE(a.w && a.wt, "vh_prep_weight: null tensor");
+    VH_REQUIRE(a.cout > 0 && a.cin > 0 && (a.taps == 1 || a.taps == 9), "vh_prep_weight: bad shape");
+    VH_REQUIRE(a.cin_pad >= a.cin && a.cin_pad % 4 == 0, "vh_prep_weight: cin_pad %d", a.cin_pad);
+    VH_REQUIRE(a.k_pad % 32 == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_prep_weight: k_pad %d", a.k_pad);
+    VH_REQUIRE(a.dst_col0 >= 0 && a.dst_col0 + a.cout <= a.dst_cols, "vh_prep_weight: destination columns out of range");
+    return vh_dispatch(ctx, [a](hipStream_t s) -> int {
+        hipLaunchKernelGGL(prep_weight_k, dim3(a.cout), dim3(256), 0, s, a);
+        return vh_check_launch("prep_weight_k");
+    });
+}
+
+extern "C" int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_pixnorm: null args");
+    const vh_pixnorm_args a = *p;
+    VH_REQUIRE(a.in && a.out, "vh_pixnorm: null tensor");
+    VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.c > 0 && a.c % 4 == 0, "vh_pixnorm: bad geometry (c must be a multiple of 4)");
+    VH_REQUIRE(vh_aligned16(a.in) && vh_aligned16(a.out), "vh_pixnorm: pointers must be 16-byte aligned");
+    const long long npix = (long long)a.rows * a.h * a.w;
+    return vh_dispatch(ctx, [a, npix](hipStream_t s) -> int {
+        hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
+        return vh_check_launch("pixnorm_k");
+    });
+}
+
+extern "C" int vh_qkv_split(vh_ctx* ctx, const vh_qkv_split_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_qkv_split: null args");
+    const vh_qkv_split_args a = *p;
+    VH_REQUIRE(a.in && a.k && a.v, "vh_qkv_split: null tensor");
+    VH_REQUIRE(a.nj == 2 || (a.nj == 3 && a.q), "vh_qkv_split: nj must be 2 or 3 (3 needs q)");
+    VH_REQUIRE(a.d == 32 || a.d == 64, "vh_qkv_split: head dim %d unsupported (32 or 64)", a.d);
+    VH_REQUIRE(a.rows > 0 && a.s > 0 && a.heads > 0 && a.rows_per_b > 0 && a.rows % a.rows_per_b == 0, "vh_qkv_split: bad geometry");
+    VH_REQUIRE(a.koff >= 0 && a.koff + a.rows_per_b * a.s <= a.kl, "vh_qkv_split: keys do not fit (koff %d + %d*%d > kl %d)", a.koff, a.rows_per_b, a.s, a.kl);
+    const long long ng = (long long)a.rows * a.s * a.heads;
+    const int d = a.d;
+    return vh_dispatch(ctx, [a, ng, d](hipStream_t s) -> int {
+        if (d == 64) hipLaunchKernelGGL(qkv_split_k<64>, dim3(blocks_for(ng, 4)), dim3(256), 0, s, a, ng);
+        else hipLaunchKernelGGL(qkv_split_k<32>, dim3(blocks_for(ng, 8)), dim3(256), 0, s, a, ng);
+        return vh_check_launch("qkv_split_k");
+    });
+}
+
+extern "C" int vh_embed(vh_ctx* ctx, const vh_embed_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_embed: null args");
+    const vh_embed_args a = *p;
+    VH_REQUIRE(a.sigma && a.freqs && a.phases && a.w_noise && a.emb, "vh_embed: null tensor");
+    VH_REQUIRE(a.cnoise > 0 && a.cnoise <= 1024 && a.cnoise <= a.w_noise_kpad, "vh_embed: cnoise %d", a.cnoise);
+    VH_REQUIRE(a.label_dim >= 0 && a.label_dim <= 64, "vh_embed: label_dim %d", a.label_dim);
+    VH_REQUIRE(!(a.geometry && a.label_dim > 0) || (a.w_label && a.label_dim <= a.w_label_kpad), "vh_embed: w_label missing");
+    VH_REQUIRE(a.rows > 0 && a.cemb > 0, "vh_embed: bad geometry");
+    return vh_dispatch(ctx, [a](hipStream_t s) -> int {
+        hipLaunchKernelGGL(embed_k, dim3(a.rows), dim3(256), 0, s, a);
+        return vh_check_launch("embed_k");
+    });
+}
+
+extern "C" int vh_linear(vh_ctx* ctx, const vh_linear_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_linear: null args");
+    const vh_linear_args a = *p;
+    VH_REQUIRE(a.emb && a.wt && a.out, "vh_linear: null tensor");
+    VH_REQUIRE(a.cemb > 0 && a.cemb <= 1024 && a.cemb % 4 == 0 && a.cemb <= a.k_pad, "vh_linear: cemb %d", a.cemb);
+    VH_REQUIRE(a.rows > 0 && a.rows < 65536 && a.cols > 0, "vh_linear: bad geometry");
+    VH_REQUIRE(vh_aligned16(a.wt), "vh_linear: weights must be 16-byte aligned");
+    return vh_dispatch(ctx, [a](hipStream_t s) -> int {
+        hipLaunchKernelGGL(linear_k, dim3(blocks_for(a.cols, 256), a.rows), dim3(256), 0, s, a);
+        return vh_check_launch("linear_k");
+    });
+}
+
+extern "C" int vh_assemble(vh_ctx* ctx, const vh_assemble_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_assemble: null args");
+    const vh_assemble_args a = *p;
+    VH_REQUIRE(a.out && a.nseg >= 1 && a.nseg <= 4, "vh_assemble: bad args");
+    int ctot = 0;
+    bool need_sigma = false;
+    for (int i = 0; i < a.nseg; ++i) {
+        VH_REQUIRE(a.seg[i].ptr && a.seg[i].c > 0 && a.seg[i].c_src >= a.seg[i].c && a.seg[i].row_mul >= 1 && (a.seg[i].kind == 0 || a.seg[i].kind == 1), "vh_assemble: bad segment %d", i);
+        ctot += a.seg[i].c;
+        need_sigma |= a.seg[i].scale_cin != 0;
+    }
+    VH_REQUIRE(!need_sigma || a.sigma, "vh_assemble: sigma missing");
+    VH_REQUIRE(a.c_pad >= ctot + 1 && a.c_pad % 4 == 0, "vh_assemble: c_pad %d too small for %d channels + ones", a.c_pad, ctot);
+    VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0, "vh_assemble: bad geometry");
+    const long long total = (long long)a.rows * a.h * a.w * a.c_pad;
+    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+        hipLaunchKernelGGL(assemble_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        return vh_check_launch("assemble_k");
+    });
+}
+
+extern "C" int vh_precond_out(vh_ctx* ctx, const vh_precond_out_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_precond_out: null args");
+    const vh_precond_out_args a = *p;
+    VH_REQUIRE(a.x && a.f && a.sigma && a.out, "vh_precond_out: null tensor");
+    VH_REQUIRE(a.rows > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.fc >= a.c && a.row_mul >= 1, "vh_precond_out: bad geometry");
+    const long long total = (long long)a.rows * a.c * a.h * a.w;
+    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+        hipLaunchKernelGGL(precond_out_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        return vh_check_launch("precond_out_k");
+    });
+}
+
+extern "C" int vh_warp_features(vh_ctx* ctx, const vh_warp_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_warp_features: null args");
+    const vh_warp_args a = *p;
+    VH_REQUIRE(a.depth && a.geometry && a.freqs && a.phases && a.grid_feat && a.warp_feat, "vh_warp_features: null tensor");
+    VH_REQUIRE(a.rows > 0 && a.s > 0 && a.depth_ch >= 0 && a.depth_ch < a.src_c, "vh_warp_features: bad geometry");
+    const long long total = (long long)a.rows * a.s * a.s * 128;
+    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+        hipLaunchKernelGGL(warp_features_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        return vh_check_launch("warp_features_k");
+    });
+}
+
+extern "C" int vh_sampler_step(vh_ctx* ctx, const vh_sampler_step_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_sampler_step: null args");
+    const vh_sampler_step_args a = *p;
+    VH_REQUIRE(a.x_hat && a.d_cond && a.d_cur && a.x_next, "vh_sampler_step: null tensor");
+    VH_REQUIRE(a.rows > 0 && a.row_mul >= 1 && a.row_elems > 0, "vh_sampler_step: bad geometry");
+    VH_REQUIRE(a.t_hat != 0.f && (!a.x_probe || a.t_next != 0.f), "vh_sampler_step: division by a zero noise level");
+    const long long total = (long long)a.rows * (long long)a.row_elems;
+    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+        hipLaunchKernelGGL(sampler_step_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        return vh_check_launch("sampler_step_k");
+    });
+}

@@ -1,0 +1,528 @@
+"""Host-side executor of the VIVID denoiser on libvivid_hip.so.
+
+Walks the block table of ``vivid_amd/arch.py`` in the order the reference's
+forward passes do (``UNetEncoder.forward`` training/models.py:536-570,
+``XAttnUNet.forward`` :483-518, ``NVPrecond._forward_dualsource`` :628-689 and
+the single-source forward :691-749) and emits C-ABI ops.  One denoiser
+evaluation for a given (mode, batch) is emitted ONCE into a ``vh_plan`` over a
+private workspace and replayed on later calls; only inputs are copied in.
+
+PyTorch is used for device memory and the stream only.  All activations live
+in one fp32 workspace tensor as NHWC buffers handed out by :class:`Arena`.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from .arch import BlockSpec, NetConfig, UNetSpec, unet_spec
+from .geometry import geometry_stats
+
+LOG2E = 1.4426950408889634
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Arena:
+    """First-fit allocator over one flat fp32 buffer (offsets in floats, 64-float granules).
+    Execution is stream-ordered, so a released range may be reused by the next op."""
+
+    GRAN = 64
+
+    def __init__(self):
+        self.free: List[List[int]] = [[0, 1 << 62]]
+        self.peak = 0
+        self.base_ptr = 0          # set once the backing tensor exists
+
+    def alloc(self, n: int) -> int:
+        n = _round_up(max(n, 1), self.GRAN)
+        for i, (off, size) in enumerate(self.free):
+            if size >= n:
+                if size == n:
+                    self.free.pop(i)
+                else:
+                    self.free[i] = [off + n, size - n]
+                self.peak = max(self.peak, off + n)
+                return off
+        raise MemoryError("arena exhausted")
+
+    def release(self, off: int, n: int):
+        n = _round_up(max(n, 1), self.GRAN)
+        self.free.append([off, n])
+        self.free.sort()
+        merged = [self.free[0]]
+        for o, s in self.free[1:]:
+            if merged[-1][0] + merged[-1][1] == o:
+                merged[-1][1] += s
+            else:
+                merged.append([o, s])
+        self.free = merged
+
+
+@dataclass
+class Buf:
+    """A workspace range viewed as [rows, h, w, c] (NHWC) or any flat shape."""
+    off: int
+    shape: Tuple[int, ...]
+    arena: Arena
+
+    @property
+    def numel(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def ptr(self) -> int:
+        return self.arena.base_ptr + 4 * self.off
+
+    def view(self, backing: torch.Tensor) -> torch.Tensor:
+        return backing[self.off:self.off + self.numel].view(self.shape)
+
+
+@dataclass
+class Weight:
+    wt: torch.Tensor
+    cin_pad: int
+    k_pad: int
+    cout: int
+    taps: int
+
+
+class Program:
+    """A recorded denoiser evaluation: plan + workspace + named I/O buffers."""
+
+    def __init__(self, plan, backing, io: Dict[str, object]):
+        self.plan, self.backing, self.io = plan, backing, io
+
+    def view(self, name):
+        b = self.io[name]
+        if isinstance(b, list):
+            return [x.view(self.backing) for x in b]
+        return b.view(self.backing)
+
+
+class Engine:
+    """Executor bound to one NVPrecond instance (its config and parameters)."""
+
+    def __init__(self, cfg: NetConfig, dual_source: bool = True):
+        self.cfg = cfg
+        self.dual = dual_source
+        self.nsrc = 2 if dual_source else 1
+        self.enc_spec: Optional[UNetSpec] = None if cfg.uncond else unet_spec(cfg, role="encoder")
+        self.unet_spec: UNetSpec = unet_spec(cfg, role="unet")
+        self.W: Dict[str, Weight] = {}
+        self.embW: Dict[str, Tuple[torch.Tensor, Dict[str, int], int]] = {}
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.programs: Dict[tuple, Program] = {}
+        self.ctx: Optional[L.Context] = None
+        self.device = None
+        self._A: Optional[Arena] = None
+        self._emit = False
+        self.hook = None
+
+    # ------------------------------------------------------------------ context / weights
+    def _ensure_ctx(self, device):
+        if self.ctx is None or self.device != device:
+            self.device = device
+            self.ctx = L.Context(torch.cuda.current_stream(device).cuda_stream)
+        else:
+            self.ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+
+    def prepare_weights(self, params: Dict[str, torch.Tensor], device):
+        """K1 once per weight version: normalise, scale by gain/sqrt(fan_in), re-lay out
+        (the reference repeats this on every forward, training/models.py:115-120)."""
+        self._ensure_ctx(device)
+        self.W.clear()
+        self.embW.clear()
+        self.programs.clear()
+        self._params = params
+        for prefix, spec in (("encoder.", self.enc_spec), ("unet.", self.unet_spec)):
+            if spec is None:
+                continue
+            self._prep_linear(prefix + "emb_noise.weight")
+            if spec.label_dim:
+                self._prep_linear(prefix + "emb_label.weight")
+            blocks = [b for b in spec.live_blocks() if b.kind == "block"]
+            total = sum(b.cout for b in blocks)
+            kpad = _round_up(spec.cemb, 32)
+            wt = torch.zeros(kpad // 4 * total * 4, dtype=torch.float32, device=device)
+            cols, c0 = {}, 0
+            for grp, b in [("enc", b) for b in spec.enc] + [("dec", b) for b in spec.dec]:
+                if not b.live:
+                    continue
+                p = f"{prefix}{grp}.{b.name}."
+                if b.kind == "conv":
+                    self._prep_conv(p + "weight", 9)
+                    continue
+                self._prep_conv(p + "conv_res0.weight", 9)
+                self._prep_conv(p + "conv_res1.weight", 9)
+                if b.cin != b.cout:
+                    self._prep_conv(p + "conv_skip.weight", 1)
+                if b.heads:
+                    self._prep_conv(p + "attn_qkv.weight", 1)
+                    self._prep_conv(p + "attn_proj.weight", 1)
+                    if b.xattn:
+                        self._prep_conv(p + "x_attn_kv.weight", 1)
+                w = params[p + "emb_linear.weight"]
+                a = L.PrepWeightArgs(w=w.data_ptr(), cout=b.cout, cin=spec.cemb, taps=1, cin_pad=_round_up(spec.cemb, 4),
+                                     k_pad=kpad, gain_ptr=params[p + "emb_gain"].data_ptr(), gain_value=1.0,
+                                     wt=wt.data_ptr(), dst_col0=c0, dst_cols=total)
+                self.ctx.call("vh_prep_weight", a)
+                cols[p] = c0
+                c0 += b.cout
+            self.embW[prefix] = (wt, cols, total)
+            if spec.out_channels:
+                self._prep_conv(prefix + "out_conv.weight", 9, gain=params[prefix + "out_gain"])
+        self._prep_linear("logvar_linear.weight")
+
+    def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None):
+        w = self._params[key]
+        cout, cin = w.shape[0], w.shape[1]
+        cin_pad = _round_up(cin, 4)
+        k_pad = _round_up(taps * cin_pad, 32)
+        wt = torch.empty(k_pad // 4 * cout * 4, dtype=torch.float32, device=w.device)
+        a = L.PrepWeightArgs(w=w.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=k_pad,
+                             gain_ptr=gain.data_ptr() if gain is not None else None, gain_value=1.0,
+                             wt=wt.data_ptr(), dst_col0=0, dst_cols=cout)
+        self.ctx.call("vh_prep_weight", a)
+        self.W[key] = Weight(wt, cin_pad, k_pad, cout, taps)
+
+    def _prep_linear(self, key: str):
+        self._prep_conv(key, 1)
+
+    # ------------------------------------------------------------------ emission helpers
+    def _alloc(self, *shape) -> Buf:
+        n = 1
+        for s in shape:
+            n *= s
+        return Buf(self._A.alloc(n), tuple(shape), self._A)
+
+    def _free(self, b: Optional[Buf]):
+        if b is not None:
+            self._A.release(b.off, b.numel)
+
+    def _call(self, name, args):
+        if self._emit:
+            self.ctx.call(name, args)
+
+    def _tap(self, name: str, buf: Buf):
+        if self._emit and self.hook is not None and self._backing is not None:
+            torch.cuda.synchronize()
+            self.hook(name, buf.view(self._backing).clone())
+
+    def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
+              cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0,
+              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None) -> Buf:
+        if out is None:
+            out = self._alloc(rows, h, w, W.cout)
+        s0, sc0 = srcs[0]
+        s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
+        a = L.ConvArgs(src0=s0.ptr, src1=s1.ptr if s1 is not None else None,
+                       c0=s0.shape[-1], c1=s1.shape[-1] if s1 is not None else 0,
+                       scale0=sc0, scale1=sc1, rows=rows, h=h, w=w, up=up, taps=W.taps, pro=pro,
+                       wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad, cout=W.cout, out=out.ptr, epi=epi,
+                       cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
+                       res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip)
+        self._call("vh_conv", a)
+        return out
+
+    def _mp_sum_coeffs(self, t: float):
+        n = math.sqrt((1 - t) ** 2 + t ** 2)
+        return (1 - t) / n, t / n
+
+    # ------------------------------------------------------------------ one block
+    def _block(self, prefix: str, grp: str, b: BlockSpec, rows: int, x: Buf, skip: Optional[Buf],
+               cvec_all: Buf, cols: Dict[str, int], total_cols: int,
+               feat: Optional[Buf], n_zero: float) -> Buf:
+        """Block.forward :165-206 / XAttnBlock.forward :251-315.  x is the block input (before
+        resampling); returns the block output.  Neither x nor skip is released here."""
+        cfg = self.cfg
+        p = f"{prefix}{grp}.{b.name}."
+        R = b.res
+        cv = (cvec_all.ptr + 4 * cols[p], total_cols)
+        ta, tb = self._mp_sum_coeffs(cfg.res_balance)
+        clip = float(cfg.clip_act) if cfg.clip_act is not None else 0.0
+        clip_res = 0.0 if b.heads else clip
+        has_skip_conv = b.cin != b.cout
+        tmp: List[Buf] = []
+        if b.flavor == "enc":
+            if b.resample == "down":
+                xn = self._alloc(rows, R, R, b.cout)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=1, norm=1))
+            elif has_skip_conv:
+                xn = self._conv([(x, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1))
+            else:
+                xn = self._alloc(rows, R, R, b.cout)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1))
+            y = self._conv([(xn, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, pro=L_PRO_SILU, epi=L_EPI_SCALE_SILU, cvec=cv)
+            out = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn,
+                             ta=ta, tb=tb, clip=clip_res)
+            self._free(y)
+            self._free(xn)
+        else:
+            up = 1 if b.resample == "up" else 0
+            if skip is not None:                                   # mp_cat :78-84
+                t = cfg.concat_balance
+                Na, Nb = x.shape[-1], skip.shape[-1]
+                Cc = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
+                srcs = [(x, Cc / math.sqrt(Na) * (1 - t)), (skip, Cc / math.sqrt(Nb) * t)]
+            else:
+                srcs = [(x, 1.0)]
+            y = self._conv(srcs, self.W[p + "conv_res0.weight"], rows, R, R, up=up, pro=L_PRO_SILU,
+                           epi=L_EPI_SCALE_SILU, cvec=cv)
+            if has_skip_conv:
+                xs = self._conv(srcs, self.W[p + "conv_skip.weight"], rows, R, R, up=up)
+                res, res_up = xs, 0
+            else:
+                assert skip is None
+                xs, res, res_up = None, x, up
+            out = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
+                             res_up=res_up, ta=ta, tb=tb, clip=clip_res)
+            self._free(y)
+            self._free(xs)
+        self._tap(p + "res", out)
+        if b.heads:
+            C = b.cout
+            D = C // b.heads
+            S = R * R
+            use_feat = b.xattn and feat is not None
+            kl = S * (1 + self.nsrc) if use_feat else S
+            nz = n_zero * S if (b.xattn and not use_feat) else 0.0
+            qkv = self._conv([(out, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R)
+            q = self._alloc(rows, b.heads, S, D)
+            k = self._alloc(rows, b.heads, kl, D)
+            v = self._alloc(rows, b.heads, kl, D)
+            self._call("vh_qkv_split", L.QkvSplitArgs(inp=qkv.ptr, rows=rows, s=S, heads=b.heads, d=D, nj=3, rows_per_b=1,
+                                                     koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
+            self._free(qkv)
+            if use_feat:
+                kv = self._conv([(feat, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R)
+                self._call("vh_qkv_split", L.QkvSplitArgs(inp=kv.ptr, rows=rows * self.nsrc, s=S, heads=b.heads, d=D, nj=2,
+                                                         rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0, q=None, k=k.ptr, v=v.ptr))
+                self._free(kv)
+            att = self._alloc(rows, R, R, C)
+            self._call("vh_attention", L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
+                                                      n_zero_keys=nz, out=att.ptr))
+            self._free(q); self._free(k); self._free(v)
+            ta2, tb2 = self._mp_sum_coeffs(cfg.attn_balance)
+            self._conv([(att, 1.0)], self.W[p + "attn_proj.weight"], rows, R, R, epi=L_EPI_MPSUM, res=out,
+                       ta=ta2, tb=tb2, clip=clip, out=out)
+            self._free(att)
+        self._tap(p + "out", out)
+        return out
+
+    # ------------------------------------------------------------------ embeddings
+    def _embedding(self, prefix: str, spec: UNetSpec, rows: int, sigma: Buf, sigma_stride: int, time_scale: float,
+                   geometry: Optional[Buf], label_dim: int) -> Tuple[Buf, Buf]:
+        P = self._params
+        emb = self._alloc(rows, spec.cemb)
+        wn = self.W[prefix + "emb_noise.weight"]
+        wl = self.W.get(prefix + "emb_label.weight")
+        has_label = wl is not None and geometry is not None
+        self._call("vh_embed", L.EmbedArgs(
+            sigma=sigma.ptr, sigma_stride=sigma_stride, time_scale=time_scale,
+            geometry=geometry.ptr if has_label else None, label_dim=label_dim if has_label else 0,
+            geometry_scale=0.0 if self.cfg.uncond else 1.0,
+            freqs=P[prefix + "emb_fourier.freqs"].data_ptr(), phases=P[prefix + "emb_fourier.phases"].data_ptr(),
+            cnoise=spec.cnoise, w_noise=wn.wt.data_ptr(), w_noise_kpad=wn.k_pad,
+            w_label=wl.wt.data_ptr() if has_label else None, w_label_kpad=wl.k_pad if has_label else 0,
+            label_balance=self.cfg.label_balance, rows=rows, cemb=spec.cemb, raw=0, emb=emb.ptr))
+        wt, cols, total = self.embW[prefix]
+        cvec = self._alloc(rows, total)
+        self._call("vh_linear", L.LinearArgs(emb=emb.ptr, rows=rows, cemb=spec.cemb, wt=wt.data_ptr(),
+                                            k_pad=_round_up(spec.cemb, 32), cols=total, bias=1.0, out=cvec.ptr))
+        self._free(emb)
+        return cvec, None
+
+    # ------------------------------------------------------------------ networks
+    def _run_unet(self, prefix: str, spec: UNetSpec, rows: int, x_in: Buf, cvec: Buf,
+                  feats: Optional[List[Buf]], collect: bool, n_zero: float):
+        """Shared walk of UNetEncoder.forward (collect=True) and XAttnUNet.forward (feats given or zero)."""
+        _, cols, total = self.embW[prefix]
+        skips: List[Buf] = []
+        out_feats: List[Buf] = []
+        fi = 0
+        x = x_in
+        for b in spec.enc:
+            if b.kind == "conv":
+                nx = self._conv([(x, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res)
+                self._tap(f"{prefix}enc.{b.name}.out", nx)
+                self._free(x)
+            else:
+                feat = None
+                if b.xattn and feats is not None:
+                    feat = feats[fi]
+                if b.xattn:
+                    fi += 1
+                nx = self._block(prefix, "enc", b, rows, x, None, cvec, cols, total, feat, n_zero)
+                if collect and b.heads > 0:
+                    out_feats.append(nx)
+            skips.append(nx)
+            x = nx
+        for b in spec.dec:
+            if not b.live:
+                break
+            skip = skips.pop() if b.takes_skip else None
+            feat = None
+            if b.xattn and feats is not None:
+                feat = feats[fi]
+            if b.xattn:
+                fi += 1
+            nx = self._block(prefix, "dec", b, rows, x, skip, cvec, cols, total, feat, n_zero)
+            keep = {id(f) for f in out_feats}
+            for old in (x, skip):
+                if old is not None and id(old) not in keep and all(old is not s for s in skips):
+                    self._free(old)
+            if collect and b.heads > 0:
+                out_feats.append(nx)
+            x = nx
+        keep = {id(f) for f in out_feats}
+        for s in skips:                               # skips the trimmed encoder-decoder never consumed
+            if id(s) not in keep and s is not x:
+                self._free(s)
+        return x, out_feats
+
+    # ------------------------------------------------------------------ program construction
+    def program(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None) -> Program:
+        """mode: 'full' (encoder + unet), 'features' (encoder only), 'inject' (unet with supplied
+        features), 'uncond' (unet, zero features in closed form)."""
+        key = (mode, B, has_cond, want_logvar)
+        if key in self.programs:
+            return self.programs[key]
+        peak = 0
+        prog = None
+        for emit in (False, True):
+            self._A = Arena()
+            self._emit = emit
+            self._backing = None
+            if emit:
+                self._backing = torch.empty(peak, dtype=torch.float32, device=self.device)
+                self._A.base_ptr = self._backing.data_ptr()
+                if self.hook is None:
+                    self.ctx.plan_begin()
+            io = self._walk(mode, B, has_cond, want_logvar, fill if emit else None)
+            if not emit:
+                peak = self._A.peak
+            else:
+                plan = self.ctx.plan_end() if self.hook is None else None
+                prog = Program(plan, self._backing, io)
+        self._emit = False
+        if self.hook is None:
+            self.programs[key] = prog
+        return prog
+
+    def _walk(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None) -> Dict[str, object]:
+        cfg = self.cfg
+        R = cfg.img_resolution
+        rm = self.nsrc if self.dual else 1          # rows per target sample in src/x/sigma/geometry
+        rows_all = B * rm
+        io: Dict[str, object] = {}
+        src_c = 3 + int(cfg.depth_input or cfg.warp_depth_coor)
+        need_enc = mode in ("full", "features")
+        need_unet = mode != "features"
+        io["sigma"] = self._alloc(rows_all)
+        io["geometry"] = self._alloc(rows_all, cfg.source_label_dim)
+        if need_enc or cfg.warp_depth_coor:
+            io["src"] = self._alloc(rows_all, src_c, R, R)
+        if need_unet:
+            io["x"] = self._alloc(rows_all, cfg.img_channels, R, R)
+            io["D"] = self._alloc(B, cfg.img_channels, R, R)
+            if has_cond:
+                io["cond"] = self._alloc(B, cfg.img_channels, R, R)
+        if want_logvar:
+            io["logvar"] = self._alloc(B)
+        feats: Optional[List[Buf]] = None
+        if mode == "inject":
+            feats = [self._alloc(rows_all, r, r, c) for (c, r) in self._feature_shapes()]
+            io["features_in"] = feats
+        if fill is not None:                  # debug (immediate) mode: inputs must be in place before ops run
+            fill(Program(None, self._backing, io))
+
+        # depth-warp Fourier features :643-652
+        sgrid = dgrid = None
+        if cfg.warp_depth_coor:
+            sgrid = self._alloc(rows_all, R, R, 128)
+            dgrid = self._alloc(rows_all, R, R, 128)
+            mean, std = geometry_stats(R)
+            wa = L.WarpArgs(depth=io["src"].ptr, src_c=src_c, depth_ch=3, geometry=io["geometry"].ptr,
+                            freqs=self._params["logvar_fourier.freqs"].data_ptr(),
+                            phases=self._params["logvar_fourier.phases"].data_ptr(),
+                            rows=rows_all, s=R, grid_feat=sgrid.ptr, warp_feat=dgrid.ptr)
+            for i in range(20):
+                wa.mean[i] = float(mean[i])
+                wa.std[i] = float(std[i])
+            self._call("vh_warp_features", wa)
+
+        if need_enc:
+            spec = self.enc_spec
+            segs = [(io["src"], 0, 3 if cfg.warp_depth_coor else src_c, src_c, 1, 0)]
+            if cfg.warp_depth_coor:
+                segs.append((sgrid, 1, 128, 128, 1, 0))
+            xin = self._assemble(segs, rows_all, R, _round_up(spec.in_channels, 4), io["sigma"])
+            self._free(sgrid)
+            sgrid = None
+            cvec, _ = self._embedding("encoder.", spec, rows_all, io["sigma"], 1, 0.0 if cfg.no_time_enc else 1.0,
+                                      io["geometry"], cfg.source_label_dim)
+            last, feats = self._run_unet("encoder.", spec, rows_all, xin, cvec, None, True, 0.0)
+            if all(last is not f for f in feats):
+                self._free(last)
+            self._free(cvec)
+            io["features_out"] = feats
+        self._free(sgrid)
+
+        if need_unet:
+            spec = self.unet_spec
+            segs = [(io["x"], 0, cfg.img_channels, cfg.img_channels, rm, 1)]
+            if cfg.warp_depth_coor:
+                segs.append((dgrid, 1, 128, 128, rm, 0))
+            if cfg.super_res:
+                assert has_cond, "super_res needs a conditioning image (:656)"
+                segs.append((io["cond"], 0, cfg.img_channels, cfg.img_channels, 1, 0))
+            xin = self._assemble(segs, B, R, _round_up(spec.in_channels, 4), io["sigma"])
+            self._free(dgrid)
+            dgrid = None
+            label_dim = cfg.target_label_dim
+            cvec, _ = self._embedding("unet.", spec, B, io["sigma"], rm, 1.0, io["geometry"], label_dim)
+            n_zero = float(self.nsrc) if (mode == "uncond") else 0.0
+            last, _ = self._run_unet("unet.", spec, B, xin, cvec, feats if mode != "uncond" else None, False, n_zero)
+            F = self._conv([(last, 1.0)], self.W["unet.out_conv.weight"], B, R, R)
+            self._free(last)
+            self._free(cvec)
+            self._call("vh_precond_out", L.PrecondOutArgs(x=io["x"].ptr, row_mul=rm, f=F.ptr, fc=F.shape[-1], sigma=io["sigma"].ptr,
+                                                         sigma_data=cfg.sigma_data, rows=B, c=cfg.img_channels, h=R, w=R, out=io["D"].ptr))
+            self._free(F)
+            if want_logvar:
+                wl = self.W["logvar_linear.weight"]
+                self._call("vh_embed", L.EmbedArgs(
+                    sigma=io["sigma"].ptr, sigma_stride=rm, time_scale=1.0, geometry=None, label_dim=0, geometry_scale=0.0,
+                    freqs=self._params["logvar_fourier.freqs"].data_ptr(), phases=self._params["logvar_fourier.phases"].data_ptr(),
+                    cnoise=cfg.logvar_channels, w_noise=wl.wt.data_ptr(), w_noise_kpad=wl.k_pad, w_label=None, w_label_kpad=0,
+                    label_balance=0.0, rows=B, cemb=1, raw=1, emb=io["logvar"].ptr))
+        self._free(dgrid)
+        return io
+
+    def _feature_shapes(self):
+        return [(b.cout, b.res) for b in self.unet_spec.enc + self.unet_spec.dec if b.kind == "block" and b.xattn]
+
+    def _assemble(self, segs, rows, R, c_pad, sigma: Buf) -> Buf:
+        out = self._alloc(rows, R, R, c_pad)
+        a = L.AssembleArgs(nseg=len(segs), sigma=sigma.ptr, sigma_data=self.cfg.sigma_data, rows=rows, h=R, w=R,
+                           c_pad=c_pad, out=out.ptr)
+        for i, (buf, kind, c, c_src, row_mul, scale) in enumerate(segs):
+            a.seg[i] = L.Segment(ptr=buf.ptr, kind=kind, c=c, c_src=c_src, row_mul=row_mul, scale_cin=scale)
+        self._call("vh_assemble", a)
+        return out
+
+
+L_PRO_SILU = 1
+L_EPI_SCALE_SILU = 1
+L_EPI_MPSUM = 2

@@ -1,0 +1,253 @@
+"""Drop-in ``NVPrecond`` backed by the HIP engine.
+
+Same constructor arguments, call protocol, attributes and state_dict key names
+as the reference's ``training.models.NVPrecond`` (training/models.py:589-749;
+SURVEY.md 8(b)), so ``edm_sampler`` / ``generate_images_nvs`` style drivers can
+use it unchanged:
+
+    net(src, dst, sigma, geometry=None, conditioning_image=None, force_fp32=False,
+        return_logvar=False, return_features=False, inject_features=None)
+
+Differences, all deliberate:
+  * compute is fp32 on gfx950 MFMA (``use_fp16`` / ``force_fp32`` are accepted and
+    ignored; the reference's fp16 mode is outside the 1e-3 parity budget);
+  * inference only (no autograd through the HIP path);
+  * the reference selects dual-source vs single-source with a module global
+    (``custom_litdata_loader.VANILLA_MODE``); here it is the ``dual_source`` argument;
+  * an ``uncond`` net accepts ``geometry=None`` and needs no features — the meaning of
+    the reference's zero-feature branch (:727-736), which HEAD's dual-source forward
+    cannot reach;
+  * there is no CPU fallback: calling the net on a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from .arch import NetConfig
+from .engine import Engine
+from .weights import state_dict_shapes
+
+
+class _Node(torch.nn.Module):
+    """Parameter container reproducing the reference's module tree (for state_dict key names)."""
+
+    def child(self, name: str) -> "_Node":
+        if name not in self._modules:
+            self.add_module(name, _Node())
+        return self._modules[name]
+
+
+class NVPrecond(torch.nn.Module):
+    def __init__(self, img_resolution, img_channels, source_label_dim, target_label_dim,
+                 use_fp16=True, sigma_data=0.5, logvar_channels=128, super_res=False, no_time_enc=None,
+                 depth_input=False, warp_depth_coor=False, uncond=None, noisy_sr=0.25,
+                 dual_source=True, **unet_kwargs):
+        super().__init__()
+        allowed = {"model_channels", "channel_mult", "num_blocks", "attn_resolutions", "extra_attn",
+                   "label_balance", "concat_balance", "res_balance", "attn_balance", "clip_act", "dropout",
+                   "epipolar_attention_bias", "channel_mult_noise", "channel_mult_emb", "resample_filter"}
+        for k in unet_kwargs:
+            if k not in allowed:
+                raise TypeError(f"NVPrecond: unexpected keyword {k!r}")
+        if unet_kwargs.get("epipolar_attention_bias"):
+            raise NotImplementedError("epipolar attention bias is dead code at HEAD (SURVEY 2.1 #13) and not built")
+        if unet_kwargs.get("channel_mult_noise") is not None or unet_kwargs.get("channel_mult_emb") is not None:
+            raise NotImplementedError("channel_mult_noise / channel_mult_emb overrides are not supported")
+        if list(unet_kwargs.get("resample_filter", [1, 1])) != [1, 1]:
+            raise NotImplementedError("only the reference's default resample_filter [1,1] is built")
+        kw = {k: v for k, v in unet_kwargs.items() if k in ("model_channels", "num_blocks", "extra_attn", "label_balance",
+                                                             "concat_balance", "res_balance", "attn_balance", "clip_act")}
+        if "channel_mult" in unet_kwargs:
+            kw["channel_mult"] = tuple(unet_kwargs["channel_mult"])
+        if "attn_resolutions" in unet_kwargs:
+            kw["attn_resolutions"] = tuple(unet_kwargs["attn_resolutions"])
+        kw.setdefault("model_channels", 192)            # UNet default, training/models.py:326
+        self.cfg = NetConfig(img_resolution=img_resolution, img_channels=img_channels,
+                             source_label_dim=source_label_dim, target_label_dim=target_label_dim,
+                             sigma_data=sigma_data, logvar_channels=logvar_channels, super_res=bool(super_res),
+                             no_time_enc=no_time_enc, depth_input=bool(depth_input), warp_depth_coor=bool(warp_depth_coor),
+                             uncond=uncond, noisy_sr=noisy_sr if noisy_sr is not None else 0.0, use_fp16=use_fp16, **kw)
+        # attributes the reference's callers read
+        self.img_resolution = img_resolution
+        self.img_channels = img_channels
+        self.use_fp16 = use_fp16
+        self.sigma_data = sigma_data
+        self.super_res = super_res
+        self.no_time_enc = no_time_enc
+        self.depth_input = depth_input
+        self.warp_depth_coor = warp_depth_coor
+        self.uncond = uncond
+        self.noisy_sr = noisy_sr
+        self.dual_source = dual_source
+
+        # parameters / buffers under the reference's names, with the reference's initialisation
+        for key, shape in state_dict_shapes(self.cfg).items():
+            *path, leaf = key.split(".")
+            node = self
+            for name in path:
+                node = node.child(name) if isinstance(node, _Node) else _Node.child(node, name)
+            if leaf == "freqs":
+                node.register_buffer(leaf, 2 * np.pi * torch.randn(shape))
+            elif leaf == "phases":
+                node.register_buffer(leaf, 2 * np.pi * torch.rand(shape))
+            elif leaf in ("emb_gain", "out_gain"):
+                node.register_parameter(leaf, torch.nn.Parameter(torch.zeros(shape)))
+            else:
+                node.register_parameter(leaf, torch.nn.Parameter(torch.randn(shape)))
+        self.requires_grad_(False)
+        self._engine = Engine(self.cfg, dual_source=dual_source)
+        self._prepared_fp = None
+        self._inject_cache = None
+
+    @classmethod
+    def from_config(cls, cfg: NetConfig, dual_source: bool = True) -> "NVPrecond":
+        return cls(img_resolution=cfg.img_resolution, img_channels=cfg.img_channels,
+                   source_label_dim=cfg.source_label_dim, target_label_dim=cfg.target_label_dim,
+                   use_fp16=cfg.use_fp16, sigma_data=cfg.sigma_data, logvar_channels=cfg.logvar_channels,
+                   super_res=cfg.super_res, no_time_enc=cfg.no_time_enc, depth_input=cfg.depth_input,
+                   warp_depth_coor=cfg.warp_depth_coor, uncond=cfg.uncond, noisy_sr=cfg.noisy_sr,
+                   dual_source=dual_source, model_channels=cfg.model_channels, channel_mult=cfg.channel_mult,
+                   num_blocks=cfg.num_blocks, attn_resolutions=cfg.attn_resolutions, extra_attn=cfg.extra_attn,
+                   label_balance=cfg.label_balance, concat_balance=cfg.concat_balance,
+                   res_balance=cfg.res_balance, attn_balance=cfg.attn_balance, clip_act=cfg.clip_act)
+
+    # -- weights ---------------------------------------------------------------------------
+    def _fingerprint(self):
+        fp = 0
+        first = None
+        for t in list(self.parameters()) + list(self.buffers()):
+            fp += t._version
+            if first is None:
+                first = t.data_ptr()
+        return (fp, first)
+
+    def _prepare(self, device):
+        fp = self._fingerprint()
+        if self._prepared_fp == fp and self._engine.device == device:
+            self._engine._ensure_ctx(device)
+            return
+        params: Dict[str, torch.Tensor] = {}
+        for k, v in self.state_dict().items():
+            if v.device != device or v.dtype != torch.float32 or not v.is_contiguous():
+                raise RuntimeError(f"NVPrecond: parameter {k} must be a contiguous fp32 tensor on {device} "
+                                   f"(got {v.dtype} on {v.device}); call net.to(device).float() first")
+            params[k] = v
+        self._engine.prepare_weights(params, device)
+        self._prepared_fp = fp
+        self._inject_cache = None
+
+    # -- forward ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, src, dst, sigma, geometry=None, conditioning_image=None, force_fp32=False,
+                return_logvar=False, return_features=False, inject_features=None, **unet_kwargs):
+        if unet_kwargs:
+            raise TypeError(f"NVPrecond.forward: unexpected keywords {sorted(unet_kwargs)}")
+        dev = dst.device
+        if dev.type != "cuda":
+            raise RuntimeError("vivid_amd.NVPrecond runs on MI355X only: inputs must be on a GPU device "
+                               "(no CPU path; use oracle/vivid_ref.py for a CPU reference)")
+        cfg, eng = self.cfg, self._engine
+        with torch.cuda.device(dev):
+            self._prepare(dev)
+            rm = 2 if self.dual_source else 1
+            rows = dst.shape[0]
+            if rows % rm:
+                raise ValueError(f"dual-source input needs an even number of rows, got {rows}")
+            B = rows // rm
+            R = cfg.img_resolution
+            src_c = 3 + int(cfg.depth_input or cfg.warp_depth_coor)
+            if tuple(dst.shape) != (rows, cfg.img_channels, R, R):
+                raise ValueError(f"dst shape {tuple(dst.shape)} != {(rows, cfg.img_channels, R, R)}")
+            if cfg.warp_depth_coor:
+                assert src.shape[1] == 4, "warp_depth_coor requires depth channel in src"      # :644
+            if cfg.super_res:
+                assert conditioning_image is not None, "super_res mode requires a conditioning_image"   # :656
+            has_cond = bool(cfg.super_res)
+            if geometry is None:
+                if not cfg.uncond and not (not self.dual_source):
+                    raise TypeError("geometry is required (the reference multiplies None by an int here, :631)")
+                geometry = torch.zeros(rows, cfg.source_label_dim, device=dev)
+            if return_features:
+                if inject_features is not None:
+                    return list(inject_features)
+                if cfg.uncond:
+                    mode = None
+                else:
+                    mode = "features"
+            elif inject_features is not None:
+                mode = "inject"
+            elif cfg.uncond:
+                mode = "uncond"
+            else:
+                mode = "full"
+            if mode is None:     # uncond net asked for features: the zero list of :727-736
+                return [torch.zeros(rows, c, r, r, device=dev) for (c, r) in eng._feature_shapes()]
+            prog = eng.program(mode, B, has_cond, bool(return_logvar))
+
+            def put(name, t, shape):
+                if tuple(t.shape) != tuple(shape):
+                    raise ValueError(f"{name} shape {tuple(t.shape)} != {tuple(shape)}")
+                prog.view(name).copy_(t.to(torch.float32))
+
+            put("sigma", sigma.reshape(-1), (rows,))
+            put("geometry", geometry.reshape(rows, -1), (rows, cfg.source_label_dim))
+            if "src" in prog.io:
+                put("src", src, (rows, src_c, R, R))
+            if "x" in prog.io:
+                put("x", dst, (rows, cfg.img_channels, R, R))
+            if "cond" in prog.io:
+                cond = conditioning_image.to(torch.float32)
+                if cfg.noisy_sr:
+                    cond = cond + cfg.noisy_sr * torch.randn_like(cond)                         # :658
+                put("cond", cond, (B, cfg.img_channels, R, R))
+            if mode == "inject":
+                key = tuple((f.data_ptr(), f._version) for f in inject_features) + (id(prog),)
+                if key != self._inject_cache:
+                    views = prog.view("features_in")
+                    if len(views) != len(inject_features):
+                        raise ValueError(f"expected {len(views)} feature maps, got {len(inject_features)}")
+                    for v, f in zip(views, inject_features):
+                        if tuple(f.shape) != (v.shape[0], v.shape[3], v.shape[1], v.shape[2]):
+                            raise ValueError(f"feature shape {tuple(f.shape)} does not match {tuple(v.shape)} (NHWC)")
+                        v.copy_(f.permute(0, 2, 3, 1))
+                    self._inject_cache = key
+            prog.plan.run()
+            if mode == "features":
+                # NCHW-shaped views over fresh NHWC storage (values and shapes as the reference's list)
+                return [v.clone().permute(0, 3, 1, 2) for v in prog.view("features_out")]
+            D = prog.view("D").clone()
+            if return_logvar:
+                return D, prog.view("logvar").clone().reshape(-1, 1, 1, 1)
+            return D
+
+    # debugging aid for tests: run once un-recorded, calling hook(name, tensor) after every block
+    @torch.no_grad()
+    def trace(self, src, dst, sigma, geometry, conditioning_image=None, hook=None):
+        dev = dst.device
+        with torch.cuda.device(dev):
+            self._prepare(dev)
+            eng = self._engine
+            rm = 2 if self.dual_source else 1
+            rows = dst.shape[0]
+            B = rows // rm
+
+            def fill(prog):
+                prog.view("sigma").copy_(sigma.reshape(-1))
+                prog.view("geometry").copy_(geometry.reshape(rows, -1))
+                if "src" in prog.io:
+                    prog.view("src").copy_(src)
+                prog.view("x").copy_(dst)
+                if "cond" in prog.io:
+                    prog.view("cond").copy_(conditioning_image)
+                torch.cuda.synchronize()
+
+            eng.hook = hook
+            try:
+                prog = eng.program("uncond" if self.cfg.uncond else "full", B, bool(self.cfg.super_res), False, fill=fill)
+                torch.cuda.synchronize()
+                return prog.view("D").clone()
+            finally:
+                eng.hook = None

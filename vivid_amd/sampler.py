@@ -1,0 +1,112 @@
+"""Guided multi-step EDM sampler with the reference's signature.
+
+Mirrors ``edm_sampler`` of the reference (``generate_images.py:43-118``): rho
+time-step discretisation (:68-70), optional churn (:78-84), Euler step and
+Heun correction (:87-114), classifier-free guidance ``ref.lerp(D, guidance)``
+(:58-62), dual-source row handling — the net returns half the rows, the update
+is applied to row 2i and copied to row 2i+1 (:90-98, :106-111) — and encoder
+feature reuse for ``no_time_enc`` nets (:52-53).  The per-step arithmetic runs in
+one HIP kernel (``vh_sampler_step``); the denoiser calls go to whatever ``net`` /
+``gnet`` are (normally :class:`vivid_amd.NVPrecond`).
+
+``StackedRandomGenerator`` mirrors ``generate_images.py:120-134``.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+_ctx = {}
+
+
+def _context(device) -> L.Context:
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    stream = torch.cuda.current_stream(device).cuda_stream
+    if key not in _ctx:
+        _ctx[key] = L.Context(stream)
+    else:
+        _ctx[key].set_stream(stream)
+    return _ctx[key]
+
+
+def _step(ctx, x_hat, x_probe, D, Dref, guidance, d_cur, t_hat, t_next, x_next):
+    rows = D.shape[0]
+    row_mul = x_hat.shape[0] // rows
+    a = L.SamplerStepArgs(x_hat=x_hat.data_ptr(), x_probe=x_probe.data_ptr() if x_probe is not None else None,
+                          d_cond=D.data_ptr(), d_ref=Dref.data_ptr() if Dref is not None else None, guidance=float(guidance),
+                          d_cur=d_cur.data_ptr(), t_hat=float(t_hat), t_next=float(t_next), rows=rows, row_mul=row_mul,
+                          row_elems=D[0].numel(), x_next=x_next.data_ptr())
+    ctx.call("vh_sampler_step", a)
+
+
+def edm_sampler(
+    net, src, noise, labels=None, gnet=None, conditioning_image=None,
+    num_steps=32, sigma_min=0.002, sigma_max=80, rho=7, guidance=1,
+    S_churn=0, S_min=0, S_max=float('inf'), S_noise=1,
+    dtype=torch.float32, randn_like=torch.randn_like,
+):
+    if dtype != torch.float32:
+        raise NotImplementedError("the HIP sampler computes in float32 (the reference's default dtype)")
+    dev = noise.device
+    if dev.type != "cuda":
+        raise RuntimeError("vivid_amd.edm_sampler runs on the GPU; inputs must be on a cuda (ROCm) device")
+    with torch.cuda.device(dev), torch.no_grad():
+        ctx = _context(dev)
+        features = None
+        if getattr(net, "no_time_enc", None):                                                   # :52-53
+            features = net(src, torch.zeros_like(src), torch.ones(src.shape[0], dtype=dtype, device=dev), labels,
+                           conditioning_image, return_features=True)
+
+        def denoise(x, t):
+            tt = torch.full((x.shape[0],), float(t), dtype=dtype, device=dev)
+            Dx = net(src, x, tt, labels, conditioning_image, inject_features=features).to(dtype).contiguous()
+            ref = gnet(src, x, tt).to(dtype).contiguous() if guidance != 1 else None            # :61
+            return Dx, ref
+
+        # Time step discretisation (:68-70), in fp32 like the reference.
+        idx = torch.arange(num_steps, dtype=dtype)
+        t_steps = (sigma_max ** (1 / rho) + idx / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+        t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])
+
+        x_next = (noise.to(dtype) * t_steps[0].item()).contiguous()
+        dual = False
+        for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+            x_cur = x_next
+            if S_churn > 0 and S_min <= t_cur <= S_max:                                           # :78-84
+                gamma = min(S_churn / num_steps, np.sqrt(2) - 1)
+                t_hat = t_cur + gamma * t_cur
+                x_hat = (x_cur + (t_hat ** 2 - t_cur ** 2).sqrt().item() * S_noise * randn_like(x_cur)).contiguous()
+            else:
+                t_hat, x_hat = t_cur, x_cur
+            D, ref = denoise(x_hat, t_hat)
+            dual = D.shape[0] != x_hat.shape[0]                                                    # :90
+            d_cur = torch.empty_like(D)
+            x_next = torch.empty_like(x_hat)
+            _step(ctx, x_hat, None, D, ref, guidance, d_cur, t_hat, t_next, x_next)              # :93-98
+            if i < num_steps - 1:                                                                  # :104-111
+                Dp, refp = denoise(x_next, t_next)
+                x_corr = torch.empty_like(x_hat)
+                _step(ctx, x_hat, x_next, Dp, refp, guidance, d_cur, t_hat, t_next, x_corr)
+                x_next = x_corr
+        return x_next[::2] if dual else x_next                                                    # :116-118
+
+
+class StackedRandomGenerator:
+    """One generator per seed, so a sample's noise depends on its seed only, not on its batch or
+    rank (generate_images.py:120-134)."""
+
+    def __init__(self, device, seeds):
+        self.generators = [torch.Generator(device).manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+
+    def randn(self, size, **kwargs):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randn(size[1:], generator=gen, **kwargs) for gen in self.generators])
+
+    def randn_like(self, input):
+        return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
+
+    def randint(self, *args, size, **kwargs):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randint(*args, size=size[1:], generator=gen, **kwargs) for gen in self.generators])
