@@ -45,6 +45,17 @@ int vh_ctx_create(void* stream, vh_ctx** out);
 int vh_ctx_destroy(vh_ctx* ctx);
 int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
 
+/* Per-kernel timing with HIP events on the launch stream (bench.py's roofline line).
+ * While enabled, every launch (direct or replayed) is bracketed by two events and carries its
+ * algorithmic FLOPs / HBM bytes; vh_profile_read synchronises the stream, sums them per
+ * kernel family (VH_TAG_*) into the caller's arrays of length ntags, and clears the records. */
+enum { VH_TAG_CONV3 = 0, VH_TAG_CONV1 = 1, VH_TAG_ATTN = 2, VH_TAG_PIXNORM = 3, VH_TAG_QKVSPLIT = 4,
+       VH_TAG_EMBED = 5, VH_TAG_ASSEMBLE = 6, VH_TAG_SAMPLER = 7, VH_TAG_PREP = 8, VH_TAG_WARP = 9, VH_NUM_TAGS = 10 };
+int vh_profile_enable(vh_ctx* ctx, int on);
+int vh_profile_read(vh_ctx* ctx, int ntags, double* ms, double* flops, double* bytes, long long* launches);
+/* Same records, one entry per launch in launch order (up to max_n); clears them. */
+int vh_profile_read_list(vh_ctx* ctx, int max_n, int* tags, double* ms, double* flops, double* bytes, int* n_out);
+
 int vh_plan_begin(vh_ctx* ctx);
 int vh_plan_end(vh_ctx* ctx, vh_plan** out);
 int vh_plan_run(vh_ctx* ctx, const vh_plan* plan);

@@ -1,0 +1,66 @@
+"""CPU, world_size 2 over gloo: the seed-sharding rule and the fp64 moment all_reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from vivid_amd import distributed as vd
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_seeds, max_batch, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    vd.init("gloo")
+    try:
+        batches = vd.rank_batches(n_seeds, max_batch)
+        g = torch.Generator().manual_seed(5)
+        feats_all = torch.randn(n_seeds, 8, generator=g)          # "feature of seed i" — same on every rank
+        st = vd.MomentStats(8)
+        for b in batches:
+            if len(b):
+                st.append(feats_all[torch.as_tensor(b)])
+            torch.distributed.barrier()                           # one barrier per batch (generate_images.py:340)
+        st.all_reduce()
+        mu, cov = st.mean_cov()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # bench.py's max-over-ranks timing
+        np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=np.concatenate(batches) if batches else np.zeros(0),
+                 mu=mu.numpy(), cov=cov.numpy(), n=int(st.n), tmax=float(t))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_seeds,max_batch", [(128, 16), (10, 4), (3, 32)])
+def test_two_rank_sharding_and_moment_allreduce(tmp_path, n_seeds, max_batch):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, n_seeds, max_batch, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"r{k}.npz") for k in range(world)]
+    idx = np.concatenate([x["idx"] for x in r]).astype(int)
+    assert sorted(idx.tolist()) == list(range(n_seeds)), "every seed exactly once across ranks"
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(n_seeds, 8, generator=g).double()
+    for x in r:
+        assert int(x["n"]) == n_seeds and x["tmax"] == 2.0
+        np.testing.assert_allclose(x["mu"], feats.mean(0).numpy(), rtol=1e-12, atol=1e-12)
+        if n_seeds > 1:
+            np.testing.assert_allclose(x["cov"], torch.cov(feats.T).numpy(), rtol=1e-10, atol=1e-12)
+
+
+def test_rank_batches_matches_reference_rule():
+    # C3 of BASELINE.json: 128 seeds, batch 16, 8 ranks -> one batch of 16 per rank
+    for rank in range(8):
+        b = vd.rank_batches(128, 16, world_size=8, rank=rank)
+        assert len(b) == 1 and len(b[0]) == 16 and b[0][0] == 16 * rank
+    # uneven: 10 seeds, max 4, 2 ranks -> 4 batches [3,3,2,2], ranks take every other one
+    a = [vd.rank_batches(10, 4, world_size=2, rank=r) for r in range(2)]
+    assert [len(x) for x in a[0]] == [3, 2] and [len(x) for x in a[1]] == [3, 2]

@@ -102,7 +102,9 @@ OPS = {
     "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
     "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs,
 }
+TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp"]
 CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",
+           "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
            "vh_plan_begin", "vh_plan_end", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
 _lib = None
@@ -123,6 +125,9 @@ def lib():
     L.vh_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.vh_ctx_destroy.argtypes = [C.c_void_p]
     L.vh_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.vh_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    L.vh_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.vh_plan_begin.argtypes = [C.c_void_p]
     L.vh_plan_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.vh_plan_run.argtypes = [C.c_void_p, C.c_void_p]
@@ -158,6 +163,27 @@ class Context:
 
     def call(self, name: str, args):
         check(getattr(self._L, name)(self.handle, C.byref(args)), name)
+
+    def profile_enable(self, on: bool):
+        check(self._L.vh_profile_enable(self.handle, 1 if on else 0), "vh_profile_enable")
+
+    def profile_read(self):
+        """{family: dict(ms, flops, bytes, launches)} accumulated since profiling was enabled / last read."""
+        n = len(TAGS)
+        ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+        ln = (C.c_longlong * n)()
+        check(self._L.vh_profile_read(self.handle, n, ms, fl, by, ln), "vh_profile_read")
+        return {TAGS[i]: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=ln[i]) for i in range(n)}
+
+    def profile_read_list(self, max_n: int = 1 << 16):
+        """[(family, ms, flops, bytes)] per launch, in launch order; clears the records."""
+        tags = (C.c_int * max_n)()
+        ms, fl, by = (C.c_double * max_n)(), (C.c_double * max_n)(), (C.c_double * max_n)()
+        n = C.c_int()
+        self._L.vh_profile_read_list.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        check(self._L.vh_profile_read_list(self.handle, max_n, tags, ms, fl, by, C.byref(n)), "vh_profile_read_list")
+        return [(TAGS[tags[i]], ms[i], fl[i], by[i]) for i in range(n.value)]
 
     def plan_begin(self):
         check(self._L.vh_plan_begin(self.handle), "vh_plan_begin")

@@ -18,10 +18,81 @@ extern "C" int vh_ctx_create(void* stream, vh_ctx** out) {
     return VH_OK;
 }
 
+static hipEvent_t vh_get_event(vh_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Launch one op; when profiling, bracket it with events on the launch stream.
+int vh_run_op(vh_ctx* ctx, const vh_op& op) {
+    if (!ctx->profiling) return op.launch(ctx->stream);
+    vh_prof_rec r{vh_get_event(ctx), vh_get_event(ctx), op.tag, op.flops, op.bytes};
+    if (!r.e0 || !r.e1) return vh_fail(VH_EHIP, "profiling: hipEventCreate failed");
+    (void)hipEventRecord(r.e0, ctx->stream);
+    const int rc = op.launch(ctx->stream);
+    (void)hipEventRecord(r.e1, ctx->stream);
+    ctx->prof.push_back(r);
+    return rc;
+}
+
 extern "C" int vh_ctx_destroy(vh_ctx* ctx) {
     if (!ctx) return VH_OK;
+    for (auto& r : ctx->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     delete ctx->cur;
     delete ctx;
+    return VH_OK;
+}
+
+extern "C" int vh_profile_enable(vh_ctx* ctx, int on) {
+    if (!ctx) return vh_fail(VH_EINVAL, "vh_profile_enable: null context");
+    if (ctx->recording) return vh_fail(VH_ESTATE, "vh_profile_enable: context is recording");
+    ctx->profiling = on != 0;
+    return VH_OK;
+}
+
+extern "C" int vh_profile_read(vh_ctx* ctx, int ntags, double* ms, double* flops, double* bytes, long long* launches) {
+    if (!ctx || !ms || !flops || !bytes || !launches) return vh_fail(VH_EINVAL, "vh_profile_read: null argument");
+    for (int i = 0; i < ntags; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_profile_read: %s", hipGetErrorString(e));
+    for (auto& r : ctx->prof) {
+        float t = 0.f;
+        e = hipEventElapsedTime(&t, r.e0, r.e1);
+        if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_profile_read: %s", hipGetErrorString(e));
+        if (r.tag >= 0 && r.tag < ntags) {
+            ms[r.tag] += t; flops[r.tag] += r.flops; bytes[r.tag] += r.bytes; launches[r.tag] += 1;
+        }
+        ctx->event_pool.push_back(r.e0);
+        ctx->event_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    return VH_OK;
+}
+
+extern "C" int vh_profile_read_list(vh_ctx* ctx, int max_n, int* tags, double* ms, double* flops, double* bytes, int* n_out) {
+    if (!ctx || !tags || !ms || !flops || !bytes || !n_out) return vh_fail(VH_EINVAL, "vh_profile_read_list: null argument");
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_profile_read_list: %s", hipGetErrorString(e));
+    int n = 0;
+    for (auto& r : ctx->prof) {
+        if (n < max_n) {
+            float t = 0.f;
+            (void)hipEventElapsedTime(&t, r.e0, r.e1);
+            tags[n] = r.tag; ms[n] = t; flops[n] = r.flops; bytes[n] = r.bytes;
+            ++n;
+        }
+        ctx->event_pool.push_back(r.e0);
+        ctx->event_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    *n_out = n;
     return VH_OK;
 }
 
@@ -52,7 +123,7 @@ extern "C" int vh_plan_run(vh_ctx* ctx, const vh_plan* plan) {
     if (!ctx || !plan) return vh_fail(VH_EINVAL, "vh_plan_run: null argument");
     if (ctx->recording) return vh_fail(VH_ESTATE, "vh_plan_run: context is recording");
     for (const auto& op : plan->ops) {
-        const int rc = op(ctx->stream);
+        const int rc = vh_run_op(ctx, op);
         if (rc != VH_OK) return rc;
     }
     return VH_OK;

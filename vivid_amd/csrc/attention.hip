@@ -214,7 +214,10 @@ extern "C" int vh_attention(vh_ctx* ctx, const vh_attention_args* p) {
     const int d = a.d;
     const int qt = a.s >= 256 ? 2 : 1;
     const dim3 grid((a.s + 128 * qt - 1) / (128 * qt), a.b * a.heads);
-    return vh_dispatch(ctx, [k, d, qt, grid](hipStream_t s) -> int {
+    const double bh = (double)a.b * a.heads;
+    const double flops = 4.0 * bh * a.s * a.kl * a.d;
+    const double bytes = 4.0 * bh * a.d * (2.0 * a.s + 2.0 * a.kl);
+    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, qt, grid](hipStream_t s) -> int {
         if (d == 64 && qt == 2) hipLaunchKernelGGL((attn_fwd_f32<64, 2>), grid, dim3(256), 0, s, k);
         else if (d == 64) hipLaunchKernelGGL((attn_fwd_f32<64, 1>), grid, dim3(256), 0, s, k);
         else if (qt == 2) hipLaunchKernelGGL((attn_fwd_f32<32, 2>), grid, dim3(256), 0, s, k);

@@ -241,7 +241,13 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
     const int taps = a.taps;
     const unsigned grid = (unsigned)(MT * NT);
-    return vh_dispatch(ctx, [k, taps, grid](hipStream_t s) -> int {
+    // algorithmic work: 2*M*cout*cin*taps FLOPs; bytes = input + weights + output (+ residual), each once
+    const double cin = (double)a.c0 + a.c1;
+    const double flops = 2.0 * (double)M * a.cout * cin * a.taps;
+    const double in_px = a.up ? (double)M / 4 : (double)M;
+    double bytes = 4.0 * (in_px * cin + cin * a.taps * a.cout + (double)M * a.cout);
+    if (a.epi == VH_EPI_MPSUM) bytes += 4.0 * (a.res_up ? (double)M / 4 : (double)M) * a.cout;
+    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, grid](hipStream_t s) -> int {
         if (taps == 9)
             hipLaunchKernelGGL(conv_igemm_f32<9>, dim3(grid), dim3(256), 0, s, k);
         else

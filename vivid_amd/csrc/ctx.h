@@ -9,15 +9,33 @@
 
 #include "../../include/vivid_hip.h"
 
+struct vh_op {
+    std::function<int(hipStream_t)> launch;
+    int tag;          // VH_TAG_*
+    double flops;     // algorithmic FLOPs of this launch
+    double bytes;     // algorithmic HBM bytes (operands read once + result written once)
+};
+
 struct vh_plan {
-    std::vector<std::function<int(hipStream_t)>> ops;
+    std::vector<vh_op> ops;
+};
+
+struct vh_prof_rec {
+    hipEvent_t e0, e1;
+    int tag;
+    double flops, bytes;
 };
 
 struct vh_ctx {
     hipStream_t stream = nullptr;
     bool recording = false;
     vh_plan* cur = nullptr;
+    bool profiling = false;
+    std::vector<vh_prof_rec> prof;          // one per launch while profiling
+    std::vector<hipEvent_t> event_pool;
 };
+
+int vh_run_op(vh_ctx* ctx, const vh_op& op);
 
 std::string& vh_err();
 
@@ -44,13 +62,14 @@ inline int vh_check_launch(const char* what) {
 
 // Launch now, or append to the plan being recorded.
 template <class F>
-inline int vh_dispatch(vh_ctx* ctx, F&& launch) {
+inline int vh_dispatch(vh_ctx* ctx, int tag, double flops, double bytes, F&& launch) {
     if (!ctx) return vh_fail(VH_EINVAL, "null context");
+    vh_op op{std::forward<F>(launch), tag, flops, bytes};
     if (ctx->recording) {
-        ctx->cur->ops.emplace_back(std::forward<F>(launch));
+        ctx->cur->ops.emplace_back(std::move(op));
         return VH_OK;
     }
-    return launch(ctx->stream);
+    return vh_run_op(ctx, op);
 }
 
 inline bool vh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

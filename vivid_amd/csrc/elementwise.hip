@@ -304,7 +304,7 @@ extern "C" int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* p) {
     VH_REQUIRE(a.cin_pad >= a.cin && a.cin_pad % 4 == 0, "vh_prep_weight: cin_pad %d", a.cin_pad);
     VH_REQUIRE(a.k_pad % 32 == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_prep_weight: k_pad %d", a.k_pad);
     VH_REQUIRE(a.dst_col0 >= 0 && a.dst_col0 + a.cout <= a.dst_cols, "vh_prep_weight: destination columns out of range");
-    return vh_dispatch(ctx, [a](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_PREP, 0.0, 4.0 * ((double)a.cout * a.cin * a.taps + (double)a.k_pad * a.cout), [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(prep_weight_k, dim3(a.cout), dim3(256), 0, s, a);
         return vh_check_launch("prep_weight_k");
     });
@@ -317,7 +317,7 @@ extern "C" int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* p) {
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.c > 0 && a.c % 4 == 0, "vh_pixnorm: bad geometry (c must be a multiple of 4)");
     VH_REQUIRE(vh_aligned16(a.in) && vh_aligned16(a.out), "vh_pixnorm: pointers must be 16-byte aligned");
     const long long npix = (long long)a.rows * a.h * a.w;
-    return vh_dispatch(ctx, [a, npix](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * (a.pool ? 5.0 : 2.0), [a, npix](hipStream_t s) -> int {
         hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
         return vh_check_launch("pixnorm_k");
     });
@@ -333,7 +333,7 @@ extern "C" int vh_qkv_split(vh_ctx* ctx, const vh_qkv_split_args* p) {
     VH_REQUIRE(a.koff >= 0 && a.koff + a.rows_per_b * a.s <= a.kl, "vh_qkv_split: keys do not fit (koff %d + %d*%d > kl %d)", a.koff, a.rows_per_b, a.s, a.kl);
     const long long ng = (long long)a.rows * a.s * a.heads;
     const int d = a.d;
-    return vh_dispatch(ctx, [a, ng, d](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_QKVSPLIT, 0.0, 8.0 * (double)ng * d * a.nj, [a, ng, d](hipStream_t s) -> int {
         if (d == 64) hipLaunchKernelGGL(qkv_split_k<64>, dim3(blocks_for(ng, 4)), dim3(256), 0, s, a, ng);
         else hipLaunchKernelGGL(qkv_split_k<32>, dim3(blocks_for(ng, 8)), dim3(256), 0, s, a, ng);
         return vh_check_launch("qkv_split_k");
@@ -348,7 +348,7 @@ extern "C" int vh_embed(vh_ctx* ctx, const vh_embed_args* p) {
     VH_REQUIRE(a.label_dim >= 0 && a.label_dim <= 64, "vh_embed: label_dim %d", a.label_dim);
     VH_REQUIRE(!(a.geometry && a.label_dim > 0) || (a.w_label && a.label_dim <= a.w_label_kpad), "vh_embed: w_label missing");
     VH_REQUIRE(a.rows > 0 && a.cemb > 0, "vh_embed: bad geometry");
-    return vh_dispatch(ctx, [a](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_EMBED, 2.0 * a.rows * (double)a.cemb * (a.cnoise + a.label_dim), 4.0 * (double)a.cemb * (a.cnoise + a.label_dim + a.rows), [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(embed_k, dim3(a.rows), dim3(256), 0, s, a);
         return vh_check_launch("embed_k");
     });
@@ -361,7 +361,7 @@ extern "C" int vh_linear(vh_ctx* ctx, const vh_linear_args* p) {
     VH_REQUIRE(a.cemb > 0 && a.cemb <= 1024 && a.cemb % 4 == 0 && a.cemb <= a.k_pad, "vh_linear: cemb %d", a.cemb);
     VH_REQUIRE(a.rows > 0 && a.rows < 65536 && a.cols > 0, "vh_linear: bad geometry");
     VH_REQUIRE(vh_aligned16(a.wt), "vh_linear: weights must be 16-byte aligned");
-    return vh_dispatch(ctx, [a](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_EMBED, 2.0 * a.rows * (double)a.cemb * a.cols, 4.0 * ((double)a.cemb * a.cols + (double)a.rows * (a.cols + a.cemb)), [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(linear_k, dim3(blocks_for(a.cols, 256), a.rows), dim3(256), 0, s, a);
         return vh_check_launch("linear_k");
     });
@@ -382,7 +382,7 @@ extern "C" int vh_assemble(vh_ctx* ctx, const vh_assemble_args* p) {
     VH_REQUIRE(a.c_pad >= ctot + 1 && a.c_pad % 4 == 0, "vh_assemble: c_pad %d too small for %d channels + ones", a.c_pad, ctot);
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0, "vh_assemble: bad geometry");
     const long long total = (long long)a.rows * a.h * a.w * a.c_pad;
-    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 8.0 * (double)total, [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(assemble_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("assemble_k");
     });
@@ -394,7 +394,7 @@ extern "C" int vh_precond_out(vh_ctx* ctx, const vh_precond_out_args* p) {
     VH_REQUIRE(a.x && a.f && a.sigma && a.out, "vh_precond_out: null tensor");
     VH_REQUIRE(a.rows > 0 && a.c > 0 && a.h > 0 && a.w > 0 && a.fc >= a.c && a.row_mul >= 1, "vh_precond_out: bad geometry");
     const long long total = (long long)a.rows * a.c * a.h * a.w;
-    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 12.0 * (double)total, [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(precond_out_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("precond_out_k");
     });
@@ -406,7 +406,7 @@ extern "C" int vh_warp_features(vh_ctx* ctx, const vh_warp_args* p) {
     VH_REQUIRE(a.depth && a.geometry && a.freqs && a.phases && a.grid_feat && a.warp_feat, "vh_warp_features: null tensor");
     VH_REQUIRE(a.rows > 0 && a.s > 0 && a.depth_ch >= 0 && a.depth_ch < a.src_c, "vh_warp_features: bad geometry");
     const long long total = (long long)a.rows * a.s * a.s * 128;
-    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_WARP, 0.0, 8.0 * (double)total, [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(warp_features_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("warp_features_k");
     });
@@ -419,7 +419,7 @@ extern "C" int vh_sampler_step(vh_ctx* ctx, const vh_sampler_step_args* p) {
     VH_REQUIRE(a.rows > 0 && a.row_mul >= 1 && a.row_elems > 0, "vh_sampler_step: bad geometry");
     VH_REQUIRE(a.t_hat != 0.f && (!a.x_probe || a.t_next != 0.f), "vh_sampler_step: division by a zero noise level");
     const long long total = (long long)a.rows * (long long)a.row_elems;
-    return vh_dispatch(ctx, [a, total](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_SAMPLER, 0.0, 4.0 * (double)total * (3.0 + a.row_mul + (a.d_ref ? 1.0 : 0.0)), [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(sampler_step_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("sampler_step_k");
     });

@@ -127,6 +127,7 @@ class Engine:
         self._A: Optional[Arena] = None
         self._emit = False
         self.hook = None
+        self.oplog: List[str] = []
 
     # ------------------------------------------------------------------ context / weights
     def _ensure_ctx(self, device):
@@ -198,6 +199,37 @@ class Engine:
     def _prep_linear(self, key: str):
         self._prep_conv(key, 1)
 
+    def measure_workspace(self, mode: str, B: int, has_cond: bool = False, want_logvar: bool = False) -> int:
+        """Workspace bytes one recorded evaluation needs (dry walk, no GPU, no launches)."""
+        saved = (self.W, self.embW, getattr(self, "_params", None))
+        if not self.W:
+            from .weights import state_dict_shapes
+            shapes = state_dict_shapes(self.cfg)
+            dummy = torch.empty(0)
+            self._params = {k: dummy for k in shapes}
+            self.W = {}
+            for k, shp in shapes.items():
+                if k.endswith("weight"):
+                    taps = 9 if len(shp) == 4 and shp[-1] == 3 else 1
+                    cin_pad = _round_up(shp[1], 4)
+                    self.W[k] = Weight(dummy, cin_pad, _round_up(taps * cin_pad, 32), shp[0], taps)
+            self.embW = {}
+            for prefix, spec in (("encoder.", self.enc_spec), ("unet.", self.unet_spec)):
+                if spec is None:
+                    continue
+                cols, c0 = {}, 0
+                for grp, b in [("enc", b) for b in spec.enc] + [("dec", b) for b in spec.dec]:
+                    if b.live and b.kind == "block":
+                        cols[f"{prefix}{grp}.{b.name}."] = c0
+                        c0 += b.cout
+                self.embW[prefix] = (dummy, cols, c0)
+        try:
+            self._A, self._emit, self._backing = Arena(), False, None
+            self._walk(mode, B, has_cond, want_logvar)
+            return 4 * self._A.peak
+        finally:
+            self.W, self.embW, self._params = saved
+
     # ------------------------------------------------------------------ emission helpers
     def _alloc(self, *shape) -> Buf:
         n = 1
@@ -209,9 +241,10 @@ class Engine:
         if b is not None:
             self._A.release(b.off, b.numel)
 
-    def _call(self, name, args):
+    def _call(self, name, args, desc: str = ""):
         if self._emit:
             self.ctx.call(name, args)
+            self.oplog.append(f"{name[3:]} {desc}")
 
     def _tap(self, name: str, buf: Buf):
         if self._emit and self.hook is not None and self._backing is not None:
@@ -231,7 +264,7 @@ class Engine:
                        wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad, cout=W.cout, out=out.ptr, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
                        res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip)
-        self._call("vh_conv", a)
+        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi}")
         return out
 
     def _mp_sum_coeffs(self, t: float):
@@ -311,7 +344,7 @@ class Engine:
                 self._free(kv)
             att = self._alloc(rows, R, R, C)
             self._call("vh_attention", L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
-                                                      n_zero_keys=nz, out=att.ptr))
+                                                      n_zero_keys=nz, out=att.ptr), f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz}")
             self._free(q); self._free(k); self._free(v)
             ta2, tb2 = self._mp_sum_coeffs(cfg.attn_balance)
             self._conv([(att, 1.0)], self.W[p + "attn_proj.weight"], rows, R, R, epi=L_EPI_MPSUM, res=out,
@@ -405,6 +438,7 @@ class Engine:
             self._emit = emit
             self._backing = None
             if emit:
+                self.oplog = []
                 self._backing = torch.empty(peak, dtype=torch.float32, device=self.device)
                 self._A.base_ptr = self._backing.data_ptr()
                 if self.hook is None:
@@ -415,6 +449,7 @@ class Engine:
             else:
                 plan = self.ctx.plan_end() if self.hook is None else None
                 prog = Program(plan, self._backing, io)
+                prog.oplog = list(self.oplog)
         self._emit = False
         if self.hook is None:
             self.programs[key] = prog
