@@ -83,9 +83,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[4];
+    unsigned okm = 0;          // bit i: the i-th staged A chunk is inside the image / channel range
     float rsc = 1.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+    // Loads are unconditional (clamped to a valid address) and zeroed by a select afterwards, so the
+    // eight global loads of a K-tile issue back to back with no branches and stay in flight over the MFMAs.
     auto load_tile = [&](int kt) {
         const int k0 = kt * BK + k4a * 4;
         const int tap = (TAPS == 1) ? (k0 >= a.cin_pad ? 1 : 0) : k0 / a.cin_pad;
@@ -96,32 +99,31 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
             dy = ty - 1;
             dx = tap - ty * 3 - 1;
         }
-        const float* sp;
-        int cs, cc;
-        bool chok = tap < TAPS;
-        if (ci < a.c0) {
-            sp = a.src0; cs = a.c0; cc = ci; rsc = a.scale0;
-        } else {
-            sp = a.src1; cs = a.c1; cc = ci - a.c0; rsc = a.scale1;
-            chok = chok && (sp != nullptr) && (cc < a.c1);
-        }
+        const bool first = ci < a.c0;
+        const float* sp = first ? a.src0 : a.src1;
+        const int cs = first ? a.c0 : a.c1;
+        int cc = first ? ci : ci - a.c0;
+        rsc = first ? a.scale0 : a.scale1;
+        bool chok = (tap < TAPS) && (first || (a.src1 != nullptr && cc < a.c1));
+        if (!chok) { sp = a.src0; cc = 0; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = py[i] + dy, xx = px[i] + dx;
             const bool ok = pv[i] && chok && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
-            const size_t pix = (size_t)(pbase[i] + (yy >> a.up) * Ws + (xx >> a.up));
-            ra[i] = ok ? *reinterpret_cast<const float4*>(sp + pix * cs + cc) : zero4;
+            const size_t pix = ok ? (size_t)(pbase[i] + (yy >> a.up) * Ws + (xx >> a.up)) : 0;
+            ra[i] = *reinterpret_cast<const float4*>(sp + pix * (chok ? cs : 0) + cc);
+            okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            rb[i] = nvalid ? wptr[(size_t)(kt * K4 + 2 * i) * a.cout] : zero4;
+        for (int i = 0; i < 4; ++i) rb[i] = wptr[(size_t)(kt * K4 + 2 * i) * a.cout];
     };
 
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 v = ra[i];
-            v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;
+            const float sc = (okm >> i) & 1u ? rsc : 0.f;       // zero padding: silu(0) = 0
+            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
             if (a.pro == VH_PRO_SILU) {
                 v.x = mp_silu_dev(v.x); v.y = mp_silu_dev(v.y);
                 v.z = mp_silu_dev(v.z); v.w = mp_silu_dev(v.w);
@@ -129,7 +131,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
             sA[buf][k4a * BM + ((ma + 32 * i) ^ k4a)] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sB[buf][(k4b + 2 * i) * BN + nb] = rb[i];
+        for (int i = 0; i < 4; ++i) {
+            float4 v = rb[i];
+            if (!nvalid) v = zero4;
+            sB[buf][(k4b + 2 * i) * BN + nb] = v;
+        }
     };
 
     const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
