@@ -50,7 +50,8 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * algorithmic FLOPs / HBM bytes; vh_profile_read synchronises the stream, sums them per
  * kernel family (VH_TAG_*) into the caller's arrays of length ntags, and clears the records. */
 enum { VH_TAG_CONV3 = 0, VH_TAG_CONV1 = 1, VH_TAG_ATTN = 2, VH_TAG_PIXNORM = 3, VH_TAG_QKVSPLIT = 4,
-       VH_TAG_EMBED = 5, VH_TAG_ASSEMBLE = 6, VH_TAG_SAMPLER = 7, VH_TAG_PREP = 8, VH_TAG_WARP = 9, VH_NUM_TAGS = 10 };
+       VH_TAG_EMBED = 5, VH_TAG_ASSEMBLE = 6, VH_TAG_SAMPLER = 7, VH_TAG_PREP = 8, VH_TAG_WARP = 9, VH_TAG_SPLIT = 10,
+       VH_NUM_TAGS = 11 };
 int vh_profile_enable(vh_ctx* ctx, int on);
 int vh_profile_read(vh_ctx* ctx, int ntags, double* ms, double* flops, double* bytes, long long* launches);
 /* Same records, one entry per launch in launch order (up to max_n); clears them. */
@@ -79,6 +80,7 @@ typedef struct {
     float gain_value;
     float* wt;           /* [k_pad/4][dst_cols][4] */
     int dst_col0, dst_cols;
+    int split;           /* 1: bf16 hi/lo split, wt[(k/8)*2 + hl][dst_cols][8 bf16], hl = 0 hi / 1 lo (same byte count) */
 } vh_prep_weight_args;
 int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* a);
 
@@ -95,6 +97,12 @@ int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* a);
  *             VH_EPI_MPSUM       clip(res[m][o]*ta + y*tb, +-clip)       (mp_sum :72-73, clip :204-205)
  *                                res_up=1 reads res at half resolution (the block input of an 'up' block).
  * fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate). */
+enum { VH_PREC_F32 = 0, VH_PREC_BF16X3 = 1 };
+/* VH_PREC_BF16X3: fp32 emulated by a bf16 hi/lo split (x = hi + lo; a*b ~= ah*bh + ah*bl + al*bh on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulate).  The source must be in the "S8" layout: per pixel, per group
+ * of 8 channels, 8 bf16 hi followed by 8 bf16 lo (4 bytes per channel, channel count a multiple of 32, pad
+ * channels zero), produced by vh_split / vh_pixnorm / a vh_conv S8 epilogue; weights from vh_prep_weight
+ * with split=1.  Scaling, mp_silu and the mp_cat concat are applied by the producer of the S8 tensor. */
 enum { VH_PRO_NONE = 0, VH_PRO_SILU = 1 };
 enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2 };
 typedef struct {
@@ -107,7 +115,9 @@ typedef struct {
     int pro;
     const float* wt; int cin_pad, k_pad;   /* from vh_prep_weight */
     int cout;
-    float* out;                            /* [rows*h*w][cout] */
+    float* out;                            /* [rows*h*w][cout] fp32; may be NULL if out_s8 is given */
+    void* out_s8; int out_s8_c;            /* optional S8 copy of the result (cout % 32 == 0, out_s8_c == cout) */
+    int prec;                              /* VH_PREC_* */
     int epi;
     const float* cvec; int cvec_ld;        /* SCALE_SILU: cvec[row*cvec_ld + o] */
     const float* res; int res_up;          /* MPSUM */
@@ -124,8 +134,21 @@ typedef struct {
     int rows, h, w, c;
     int pool;
     int norm;     /* 0: pooling only */
+    void* out_s8; /* optional: mp_silu(out) in the S8 layout (c % 32 == 0), the conv_res0 input of :174 */
 } vh_pixnorm_args;
 int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* a);
+
+/* ---- fp32 NHWC -> S8 (bf16 hi/lo split) with the conv_res0 prologue -----
+ * out = split( pro( concat(scale0*src0, scale1*src1) ) ), zero-padded to c_pad channels (multiple of 32):
+ * mp_cat :78-84 and mp_silu :66-67,:174 applied once per element instead of once per tap. */
+typedef struct {
+    const float* src0; const float* src1;  /* src1 may be NULL */
+    int c0, c1; float scale0, scale1;
+    int pro;                               /* VH_PRO_* */
+    long long npix; int c_pad;
+    void* out;
+} vh_split_args;
+int vh_split(vh_ctx* ctx, const vh_split_args* a);
 
 /* ---- K11 part 1: q/k/v split + per-head vector norm -----------------------
  * The view/normalize/unbind of :192-194, :279-293: the 1x1-conv output has channel

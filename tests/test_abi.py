@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_mirrors_match_header_field_counts():
     h = _header()
     pairs = {"vh_prep_weight_args": _lib.PrepWeightArgs, "vh_conv_args": _lib.ConvArgs, "vh_pixnorm_args": _lib.PixnormArgs,
-             "vh_qkv_split_args": _lib.QkvSplitArgs, "vh_attention_args": _lib.AttentionArgs, "vh_embed_args": _lib.EmbedArgs,
+             "vh_qkv_split_args": _lib.QkvSplitArgs, "vh_split_args": _lib.SplitArgs, "vh_attention_args": _lib.AttentionArgs, "vh_embed_args": _lib.EmbedArgs,
              "vh_linear_args": _lib.LinearArgs, "vh_segment": _lib.Segment, "vh_assemble_args": _lib.AssembleArgs,
              "vh_precond_out_args": _lib.PrecondOutArgs, "vh_warp_args": _lib.WarpArgs,
              "vh_sampler_step_args": _lib.SamplerStepArgs}

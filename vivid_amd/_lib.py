@@ -22,7 +22,8 @@ class VividHipError(RuntimeError):
 class PrepWeightArgs(C.Structure):
     _fields_ = [("w", C.c_void_p), ("cout", C.c_int), ("cin", C.c_int), ("taps", C.c_int),
                 ("cin_pad", C.c_int), ("k_pad", C.c_int), ("gain_ptr", C.c_void_p),
-                ("gain_value", C.c_float), ("wt", C.c_void_p), ("dst_col0", C.c_int), ("dst_cols", C.c_int)]
+                ("gain_value", C.c_float), ("wt", C.c_void_p), ("dst_col0", C.c_int), ("dst_cols", C.c_int),
+                ("split", C.c_int)]
 
 
 class ConvArgs(C.Structure):
@@ -30,14 +31,21 @@ class ConvArgs(C.Structure):
                 ("scale0", C.c_float), ("scale1", C.c_float),
                 ("rows", C.c_int), ("h", C.c_int), ("w", C.c_int), ("up", C.c_int), ("taps", C.c_int),
                 ("pro", C.c_int), ("wt", C.c_void_p), ("cin_pad", C.c_int), ("k_pad", C.c_int),
-                ("cout", C.c_int), ("out", C.c_void_p), ("epi", C.c_int),
+                ("cout", C.c_int), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
+                ("prec", C.c_int), ("epi", C.c_int),
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
                 ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float)]
 
 
 class PixnormArgs(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("h", C.c_int),
-                ("w", C.c_int), ("c", C.c_int), ("pool", C.c_int), ("norm", C.c_int)]
+                ("w", C.c_int), ("c", C.c_int), ("pool", C.c_int), ("norm", C.c_int), ("out_s8", C.c_void_p)]
+
+
+class SplitArgs(C.Structure):
+    _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+                ("scale0", C.c_float), ("scale1", C.c_float), ("pro", C.c_int), ("npix", C.c_longlong),
+                ("c_pad", C.c_int), ("out", C.c_void_p)]
 
 
 class QkvSplitArgs(C.Structure):
@@ -97,12 +105,12 @@ class SamplerStepArgs(C.Structure):
 
 # every symbol include/vivid_hip.h declares: name -> (args struct or None)
 OPS = {
-    "vh_prep_weight": PrepWeightArgs, "vh_conv": ConvArgs, "vh_pixnorm": PixnormArgs,
+    "vh_prep_weight": PrepWeightArgs, "vh_conv": ConvArgs, "vh_pixnorm": PixnormArgs, "vh_split": SplitArgs,
     "vh_qkv_split": QkvSplitArgs, "vh_attention": AttentionArgs, "vh_embed": EmbedArgs,
     "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
     "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs,
 }
-TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp"]
+TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
 CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
            "vh_plan_begin", "vh_plan_end", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]

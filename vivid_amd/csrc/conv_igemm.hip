@@ -17,11 +17,22 @@
 //   two lane halves supply k = 8kg+j and 8kg+4+j — a permutation of k that A and B share.
 //   The XOR keeps the 8 staging lanes that hold the same pixel (different k4) on different
 //   16-byte slots (ds_write_b128 is serviced 8 lanes at a time); reads stay conflict-free.
+// Two arithmetic modes share all staging code (template parameter PREC):
+//   VH_PREC_F32    — fp32 operands, v_mfma_f32_32x32x2_f32 (exact fp32 products);
+//   VH_PREC_BF16X3 — fp32 emulated by a bf16 hi/lo split: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)),
+//                    a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32
+//                    accumulation (3 MFMAs per 16-deep k-slab instead of 8 fp32 ones: 5.3x the matrix rate;
+//                    per-product relative error <= ~2^-16, gfx950 has no xf32).  Activations arrive
+//                    pre-split in the "S8" layout (per pixel, per 8 channels: 8 bf16 hi then 8 bf16 lo —
+//                    the same 4 bytes/channel as fp32, so the 16-byte staging units and their addresses
+//                    are identical), written by the producing kernel's epilogue / vh_split / vh_pixnorm;
+//                    weights are pre-split by vh_prep_weight.  LDS unit u = 2*(8-channel chunk) + {hi,lo}.
 // Pipeline: global -> registers for tile t+1 is issued before the MFMAs of tile t, written
 //   to the other LDS buffer after them; one barrier per K-tile.
 #include "ctx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -32,7 +43,7 @@ struct ConvK {
     int c0, c1; float scale0, scale1;
     int h, w, up, pro;
     const float4* wt; int cin_pad, k_pad, cout;
-    float* out; int epi;
+    float* out; unsigned short* out_s8; int out_s8_c; int epi;
     const float* cvec; int cvec_ld;
     const float* res; int res_up;
     float ta, tb, clip;
@@ -45,8 +56,22 @@ __device__ __forceinline__ float mp_silu_dev(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
 }
 
-template <int TAPS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
+__device__ __forceinline__ unsigned bf16_rn_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// x ~= hi + lo, both bf16 (round to nearest even); written into the S8 layout.
+__device__ __forceinline__ void store_s8(unsigned short* base, size_t pix, int cpad, int ch, float v) {
+    const unsigned hi = bf16_rn_bits(v);
+    const unsigned lo = bf16_rn_bits(v - __uint_as_float(hi << 16));
+    unsigned short* p = base + (pix * cpad + (size_t)(ch & ~7)) * 2 + (ch & 7);
+    p[0] = (unsigned short)hi;
+    p[8] = (unsigned short)lo;
+}
+
+template <int TAPS, int PREC>
+__global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
     __shared__ float4 sA[2][K4 * BM];
     __shared__ float4 sB[2][K4 * BN];
 
@@ -122,11 +147,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 v = ra[i];
-            const float sc = (okm >> i) & 1u ? rsc : 0.f;       // zero padding: silu(0) = 0
-            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-            if (a.pro == VH_PRO_SILU) {
-                v.x = mp_silu_dev(v.x); v.y = mp_silu_dev(v.y);
-                v.z = mp_silu_dev(v.z); v.w = mp_silu_dev(v.w);
+            if constexpr (PREC == VH_PREC_F32) {
+                const float sc = (okm >> i) & 1u ? rsc : 0.f;       // zero padding: silu(0) = 0
+                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                if (a.pro == VH_PRO_SILU) {
+                    v.x = mp_silu_dev(v.x); v.y = mp_silu_dev(v.y);
+                    v.z = mp_silu_dev(v.z); v.w = mp_silu_dev(v.w);
+                }
+            } else {
+                if (!((okm >> i) & 1u)) v = zero4;                  // raw bf16 pairs: select, never multiply
             }
             sA[buf][k4a * BM + ((ma + 32 * i) ^ k4a)] = v;
         }
@@ -142,25 +171,54 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
     const int wm = wv >> 1, wn = wv & 1;
 
     auto compute = [&](int buf) {
+        if constexpr (PREC == VH_PREC_F32) {
 #pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-            const int k4 = kg * 2 + hh;
-            float4 af[2], bf[2];
+            for (int kg = 0; kg < BK / 8; ++kg) {
+                const int k4 = kg * 2 + hh;
+                float4 af[2], bf[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) af[mi] = sA[buf][k4 * BM + ((wm * 64 + mi * 32 + lr) ^ k4)];
+                for (int mi = 0; mi < 2; ++mi) af[mi] = sA[buf][k4 * BM + ((wm * 64 + mi * 32 + lr) ^ k4)];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) bf[ni] = sB[buf][k4 * BN + wn * 64 + ni * 32 + lr];
+                for (int ni = 0; ni < 2; ++ni) bf[ni] = sB[buf][k4 * BN + wn * 64 + ni * 32 + lr];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    const float av = j == 0 ? af[mi].x : j == 1 ? af[mi].y : j == 2 ? af[mi].z : af[mi].w;
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const float av = j == 0 ? af[mi].x : j == 1 ? af[mi].y : j == 2 ? af[mi].z : af[mi].w;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const float bv = j == 0 ? bf[ni].x : j == 1 ? bf[ni].y : j == 2 ? bf[ni].z : bf[ni].w;
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+                        for (int ni = 0; ni < 2; ++ni) {
+                            const float bv = j == 0 ? bf[ni].x : j == 1 ? bf[ni].y : j == 2 ? bf[ni].z : bf[ni].w;
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[mi][ni], 0, 0, 0);
+                        }
                     }
                 }
+            }
+        } else {
+            // 32x32x16 bf16: lane (row = l&31, h = l>>5) supplies k = 8h..8h+7 of the slab = chunk 2*slab + h.
+#pragma unroll
+            for (int sl = 0; sl < BK / 16; ++sl) {
+                const int uh = (sl * 2 + hh) * 2, ul = uh + 1;
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int m = wm * 64 + mi * 32 + lr;
+                    ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[buf][uh * BM + (m ^ uh)]);
+                    al[mi] = *reinterpret_cast<const bf16x8*>(&sA[buf][ul * BM + (m ^ ul)]);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int n = wn * 64 + ni * 32 + lr;
+                    bh[ni] = *reinterpret_cast<const bf16x8*>(&sB[buf][uh * BN + n]);
+                    bl[ni] = *reinterpret_cast<const bf16x8*>(&sB[buf][ul * BN + n]);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
             }
         }
     };
@@ -208,7 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_f32(const ConvK a) {
                     y = a.res[rrow * a.cout + gn] * a.ta + y * a.tb;
                     if (a.clip > 0.f) y = fminf(fmaxf(y, -a.clip), a.clip);
                 }
-                a.out[(size_t)gm * a.cout + gn] = y;
+                if (a.out) a.out[(size_t)gm * a.cout + gn] = y;
+                if (a.out_s8) store_s8(a.out_s8, (size_t)gm, a.out_s8_c, gn, y);
             }
         }
     }
@@ -220,7 +279,13 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_conv: null args");
     const vh_conv_args a = *p;
     VH_REQUIRE(a.taps == 1 || a.taps == 9, "vh_conv: taps must be 1 or 9 (got %d)", a.taps);
-    VH_REQUIRE(a.src0 && a.wt && a.out, "vh_conv: null tensor");
+    VH_REQUIRE(a.src0 && a.wt && (a.out || a.out_s8), "vh_conv: null tensor");
+    VH_REQUIRE(a.prec == VH_PREC_F32 || a.prec == VH_PREC_BF16X3, "vh_conv: bad prec %d", a.prec);
+    if (a.prec == VH_PREC_BF16X3) {
+        VH_REQUIRE(!a.src1 && a.pro == VH_PRO_NONE && a.scale0 == 1.0f, "vh_conv: bf16x3 takes one pre-split (S8) source; scale/silu/concat belong to its producer");
+        VH_REQUIRE(a.c0 % 32 == 0 && a.cin_pad == a.c0, "vh_conv: bf16x3 needs c0 == cin_pad, a multiple of 32 (got %d, %d)", a.c0, a.cin_pad);
+    }
+    VH_REQUIRE(!a.out_s8 || (a.cout % 32 == 0 && a.out_s8_c == a.cout), "vh_conv: S8 output needs cout %% 32 == 0 and out_s8_c == cout");
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.cout > 0, "vh_conv: bad geometry");
     VH_REQUIRE(a.c0 > 0 && a.c0 % 4 == 0, "vh_conv: c0 must be a positive multiple of 4 (got %d)", a.c0);
     VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 4 == 0) : a.c1 == 0, "vh_conv: bad c1 %d", a.c1);
@@ -242,10 +307,10 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.src0 = a.src0; k.src1 = a.src1; k.c0 = a.c0; k.c1 = a.c1; k.scale0 = a.scale0; k.scale1 = a.scale1;
     k.h = a.h; k.w = a.w; k.up = a.up ? 1 : 0; k.pro = a.pro;
     k.wt = reinterpret_cast<const float4*>(a.wt); k.cin_pad = a.cin_pad; k.k_pad = a.k_pad; k.cout = a.cout;
-    k.out = a.out; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;
+    k.out = a.out; k.out_s8 = static_cast<unsigned short*>(a.out_s8); k.out_s8_c = a.out_s8_c; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;
     k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
-    const int taps = a.taps;
+    const int taps = a.taps, prec = a.prec;
     const unsigned grid = (unsigned)(MT * NT);
     // algorithmic work: 2*M*cout*cin*taps FLOPs; bytes = input + weights + output (+ residual), each once
     const double cin = (double)a.c0 + a.c1;
@@ -253,11 +318,14 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     const double in_px = a.up ? (double)M / 4 : (double)M;
     double bytes = 4.0 * (in_px * cin + cin * a.taps * a.cout + (double)M * a.cout);
     if (a.epi == VH_EPI_MPSUM) bytes += 4.0 * (a.res_up ? (double)M / 4 : (double)M) * a.cout;
-    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, grid](hipStream_t s) -> int {
-        if (taps == 9)
-            hipLaunchKernelGGL(conv_igemm_f32<9>, dim3(grid), dim3(256), 0, s, k);
-        else
-            hipLaunchKernelGGL(conv_igemm_f32<1>, dim3(grid), dim3(256), 0, s, k);
-        return vh_check_launch("conv_igemm_f32");
+    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, prec, grid](hipStream_t s) -> int {
+        if (prec == VH_PREC_BF16X3) {
+            if (taps == 9) hipLaunchKernelGGL((conv_igemm<9, VH_PREC_BF16X3>), dim3(grid), dim3(256), 0, s, k);
+            else hipLaunchKernelGGL((conv_igemm<1, VH_PREC_BF16X3>), dim3(grid), dim3(256), 0, s, k);
+        } else {
+            if (taps == 9) hipLaunchKernelGGL((conv_igemm<9, VH_PREC_F32>), dim3(grid), dim3(256), 0, s, k);
+            else hipLaunchKernelGGL((conv_igemm<1, VH_PREC_F32>), dim3(grid), dim3(256), 0, s, k);
+        }
+        return vh_check_launch("conv_igemm");
     });
 }

@@ -27,6 +27,15 @@ __device__ __forceinline__ float mp_silu_dev(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
 }
 
+__device__ __forceinline__ unsigned bf16_rn_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void split_bf16(float v, unsigned& hi, unsigned& lo) {
+    hi = bf16_rn_bits(v);
+    lo = bf16_rn_bits(v - __uint_as_float(hi << 16));
+}
+
 // ---------------------------------------------------------------- weight prep
 __global__ __launch_bounds__(256) void prep_weight_k(vh_prep_weight_args a) {
     __shared__ float red[4];
@@ -43,7 +52,16 @@ __global__ __launch_bounds__(256) void prep_weight_k(vh_prep_weight_args a) {
         const int tap = k / a.cin_pad, ci = k - tap * a.cin_pad;
         float v = 0.f;
         if (tap < a.taps && ci < a.cin) v = w[ci * a.taps + tap] * scale;
-        a.wt[((size_t)(k >> 2) * a.dst_cols + a.dst_col0 + o) * 4 + (k & 3)] = v;
+        if (a.split) {
+            unsigned hi, lo;
+            split_bf16(v, hi, lo);
+            unsigned short* ws = reinterpret_cast<unsigned short*>(a.wt);
+            const size_t u = (size_t)(k >> 3) * 2;
+            ws[((u + 0) * a.dst_cols + a.dst_col0 + o) * 8 + (k & 7)] = (unsigned short)hi;
+            ws[((u + 1) * a.dst_cols + a.dst_col0 + o) * 8 + (k & 7)] = (unsigned short)lo;
+        } else {
+            a.wt[((size_t)(k >> 2) * a.dst_cols + a.dst_col0 + o) * 4 + (k & 3)] = v;
+        }
     }
 }
 
@@ -91,11 +109,52 @@ __global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long np
         ss = wave_sum(ss);
         scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
     }
+    unsigned short* s8 = a.out_s8 ? static_cast<unsigned short*>(a.out_s8) + (size_t)p * a.c * 2 : nullptr;
     for (int i = lane; i < c4; i += 64) {
         float4 v = fetch(i);
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
         dst[i] = v;
+        if (s8) {       // mp_silu(out), bf16 hi/lo: chunk of 8 channels = [hi x8 | lo x8], this float4 is half of one
+            const float e[4] = {mp_silu_dev(v.x), mp_silu_dev(v.y), mp_silu_dev(v.z), mp_silu_dev(v.w)};
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) split_bf16(e[j], h[j], l[j]);
+            unsigned short* q = s8 + (size_t)(i >> 1) * 16 + (i & 1) * 4;
+            *reinterpret_cast<uint2*>(q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(q + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        }
     }
+}
+
+// ---------------------------------------------------------------- fp32 -> S8 split (+concat, scale, silu)
+// one thread per 8-channel chunk of one pixel
+__global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int nch = a.c_pad >> 3;
+    const long long pix = i / nch;
+    const int c = (int)(i - pix * nch) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    const float* sp = nullptr;
+    float sc = 1.f;
+    if (c < a.c0) { sp = a.src0 + (size_t)pix * a.c0 + c; sc = a.scale0; }
+    else if (a.src1 && c - a.c0 < a.c1) { sp = a.src1 + (size_t)pix * a.c1 + (c - a.c0); sc = a.scale1; }
+    if (sp) {
+        const float4 p0 = *reinterpret_cast<const float4*>(sp), p1 = *reinterpret_cast<const float4*>(sp + 4);
+        v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+    }
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float e = v[j] * sc;
+        if (a.pro == VH_PRO_SILU) e = mp_silu_dev(e);
+        split_bf16(e, h[j], l[j]);
+    }
+    uint4* o = reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out) + (size_t)i * 16);
+    o[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    o[1] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
 // ---------------------------------------------------------------- q/k/v split + head norm
@@ -303,10 +362,27 @@ extern "C" int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* p) {
     VH_REQUIRE(a.cout > 0 && a.cin > 0 && (a.taps == 1 || a.taps == 9), "vh_prep_weight: bad shape");
     VH_REQUIRE(a.cin_pad >= a.cin && a.cin_pad % 4 == 0, "vh_prep_weight: cin_pad %d", a.cin_pad);
     VH_REQUIRE(a.k_pad % 32 == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_prep_weight: k_pad %d", a.k_pad);
+    VH_REQUIRE(!a.split || a.cin_pad % 32 == 0, "vh_prep_weight: split weights need cin_pad %% 32 == 0 (got %d)", a.cin_pad);
     VH_REQUIRE(a.dst_col0 >= 0 && a.dst_col0 + a.cout <= a.dst_cols, "vh_prep_weight: destination columns out of range");
     return vh_dispatch(ctx, VH_TAG_PREP, 0.0, 4.0 * ((double)a.cout * a.cin * a.taps + (double)a.k_pad * a.cout), [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(prep_weight_k, dim3(a.cout), dim3(256), 0, s, a);
         return vh_check_launch("prep_weight_k");
+    });
+}
+
+extern "C" int vh_split(vh_ctx* ctx, const vh_split_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_split: null args");
+    const vh_split_args a = *p;
+    VH_REQUIRE(a.src0 && a.out, "vh_split: null tensor");
+    VH_REQUIRE(a.c0 > 0 && a.c0 % 8 == 0, "vh_split: c0 must be a positive multiple of 8 (got %d)", a.c0);
+    VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 8 == 0) : a.c1 == 0, "vh_split: bad c1 %d", a.c1);
+    VH_REQUIRE(a.c_pad % 32 == 0 && a.c_pad >= a.c0 + a.c1, "vh_split: c_pad %d must be a multiple of 32 >= %d", a.c_pad, a.c0 + a.c1);
+    VH_REQUIRE(a.npix > 0 && (a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU), "vh_split: bad arguments");
+    VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.out), "vh_split: pointers must be 16-byte aligned");
+    const long long total = a.npix * (a.c_pad / 8);
+    return vh_dispatch(ctx, VH_TAG_SPLIT, 0.0, 4.0 * (double)a.npix * ((double)a.c0 + a.c1 + a.c_pad), [a, total](hipStream_t s) -> int {
+        hipLaunchKernelGGL(split_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        return vh_check_launch("split_k");
     });
 }
 
@@ -315,9 +391,10 @@ extern "C" int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* p) {
     const vh_pixnorm_args a = *p;
     VH_REQUIRE(a.in && a.out, "vh_pixnorm: null tensor");
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.c > 0 && a.c % 4 == 0, "vh_pixnorm: bad geometry (c must be a multiple of 4)");
-    VH_REQUIRE(vh_aligned16(a.in) && vh_aligned16(a.out), "vh_pixnorm: pointers must be 16-byte aligned");
+    VH_REQUIRE(vh_aligned16(a.in) && vh_aligned16(a.out) && vh_aligned16(a.out_s8), "vh_pixnorm: pointers must be 16-byte aligned");
+    VH_REQUIRE(!a.out_s8 || a.c % 32 == 0, "vh_pixnorm: S8 output needs c %% 32 == 0 (got %d)", a.c);
     const long long npix = (long long)a.rows * a.h * a.w;
-    return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * (a.pool ? 5.0 : 2.0), [a, npix](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * ((a.pool ? 5.0 : 2.0) + (a.out_s8 ? 1.0 : 0.0)), [a, npix](hipStream_t s) -> int {
         hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
         return vh_check_launch("pixnorm_k");
     });

@@ -112,7 +112,11 @@ class Program:
 class Engine:
     """Executor bound to one NVPrecond instance (its config and parameters)."""
 
-    def __init__(self, cfg: NetConfig, dual_source: bool = True):
+    def __init__(self, cfg: NetConfig, dual_source: bool = True, precision: str = "fp32"):
+        if precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {precision!r}")
+        self.precision = precision
+        self.x3 = precision == "bf16x3"      # 3x3 convs on the bf16 hi/lo split MFMA path
         self.cfg = cfg
         self.dual = dual_source
         self.nsrc = 2 if dual_source else 1
@@ -175,7 +179,7 @@ class Engine:
                 w = params[p + "emb_linear.weight"]
                 a = L.PrepWeightArgs(w=w.data_ptr(), cout=b.cout, cin=spec.cemb, taps=1, cin_pad=_round_up(spec.cemb, 4),
                                      k_pad=kpad, gain_ptr=params[p + "emb_gain"].data_ptr(), gain_value=1.0,
-                                     wt=wt.data_ptr(), dst_col0=c0, dst_cols=total)
+                                     wt=wt.data_ptr(), dst_col0=c0, dst_cols=total, split=0)
                 self.ctx.call("vh_prep_weight", a)
                 cols[p] = c0
                 c0 += b.cout
@@ -187,12 +191,13 @@ class Engine:
     def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None):
         w = self._params[key]
         cout, cin = w.shape[0], w.shape[1]
-        cin_pad = _round_up(cin, 4)
+        split = 1 if (self.x3 and taps == 9) else 0
+        cin_pad = _round_up(cin, 32 if split else 4)
         k_pad = _round_up(taps * cin_pad, 32)
         wt = torch.empty(k_pad // 4 * cout * 4, dtype=torch.float32, device=w.device)
         a = L.PrepWeightArgs(w=w.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=k_pad,
                              gain_ptr=gain.data_ptr() if gain is not None else None, gain_value=1.0,
-                             wt=wt.data_ptr(), dst_col0=0, dst_cols=cout)
+                             wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=split)
         self.ctx.call("vh_prep_weight", a)
         self.W[key] = Weight(wt, cin_pad, k_pad, cout, taps)
 
@@ -211,7 +216,7 @@ class Engine:
             for k, shp in shapes.items():
                 if k.endswith("weight"):
                     taps = 9 if len(shp) == 4 and shp[-1] == 3 else 1
-                    cin_pad = _round_up(shp[1], 4)
+                    cin_pad = _round_up(shp[1], 32 if (self.x3 and taps == 9) else 4)
                     self.W[k] = Weight(dummy, cin_pad, _round_up(taps * cin_pad, 32), shp[0], taps)
             self.embW = {}
             for prefix, spec in (("encoder.", self.enc_spec), ("unet.", self.unet_spec)):
@@ -253,18 +258,37 @@ class Engine:
 
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
               cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0,
-              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None) -> Buf:
-        if out is None:
+              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False) -> Buf:
+        """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8."""
+        out_s8 = None
+        if s8_only:
+            out_s8 = self._alloc(rows, h, w, W.cout)
+        elif out is None:
             out = self._alloc(rows, h, w, W.cout)
         s0, sc0 = srcs[0]
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
         a = L.ConvArgs(src0=s0.ptr, src1=s1.ptr if s1 is not None else None,
                        c0=s0.shape[-1], c1=s1.shape[-1] if s1 is not None else 0,
                        scale0=sc0, scale1=sc1, rows=rows, h=h, w=w, up=up, taps=W.taps, pro=pro,
-                       wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad, cout=W.cout, out=out.ptr, epi=epi,
+                       wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad, cout=W.cout,
+                       out=out.ptr if out is not None else None, out_s8=out_s8.ptr if out_s8 is not None else None,
+                       out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
                        res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip)
-        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi}")
+        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}")
+        return out_s8 if s8_only else out
+
+    def _split(self, srcs: Sequence[Tuple[Buf, float]], pro: int) -> Buf:
+        """fp32 NHWC (1-2 sources, mp_cat weights) -> S8 at the sources' resolution, channels padded to 32."""
+        s0, sc0 = srcs[0]
+        s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
+        rows, h, w = s0.shape[:3]
+        ctot = s0.shape[-1] + (s1.shape[-1] if s1 is not None else 0)
+        cpad = _round_up(ctot, 32)
+        out = self._alloc(rows, h, w, cpad)
+        self._call("vh_split", L.SplitArgs(src0=s0.ptr, src1=s1.ptr if s1 is not None else None, c0=s0.shape[-1],
+                                          c1=s1.shape[-1] if s1 is not None else 0, scale0=sc0, scale1=sc1, pro=pro,
+                                          npix=rows * h * w, c_pad=cpad, out=out.ptr), f"rows={rows} {h}x{w} c={ctot}")
         return out
 
     def _mp_sum_coeffs(self, t: float):
@@ -286,19 +310,27 @@ class Engine:
         clip_res = 0.0 if b.heads else clip
         has_skip_conv = b.cin != b.cout
         tmp: List[Buf] = []
+        x3 = self.x3 and b.cout % 32 == 0
+        P1 = 1 if x3 else 0
         if b.flavor == "enc":
+            xs = self._alloc(rows, R, R, b.cout) if x3 else None      # S8 of mp_silu(xn): conv_res0's input
+            xs_ptr = xs.ptr if xs is not None else None
             if b.resample == "down":
                 xn = self._alloc(rows, R, R, b.cout)
-                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=1, norm=1))
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=1, norm=1, out_s8=xs_ptr))
             elif has_skip_conv:
                 xn = self._conv([(x, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R)
-                self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1))
+                self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1, out_s8=xs_ptr))
             else:
                 xn = self._alloc(rows, R, R, b.cout)
-                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1))
-            y = self._conv([(xn, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, pro=L_PRO_SILU, epi=L_EPI_SCALE_SILU, cvec=cv)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1, out_s8=xs_ptr))
+            if x3:
+                y = self._conv([(xs, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True)
+                self._free(xs)
+            else:
+                y = self._conv([(xn, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, pro=L_PRO_SILU, epi=L_EPI_SCALE_SILU, cvec=cv)
             out = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn,
-                             ta=ta, tb=tb, clip=clip_res)
+                             ta=ta, tb=tb, clip=clip_res, prec=P1)
             self._free(y)
             self._free(xn)
         else:
@@ -310,8 +342,14 @@ class Engine:
                 srcs = [(x, Cc / math.sqrt(Na) * (1 - t)), (skip, Cc / math.sqrt(Nb) * t)]
             else:
                 srcs = [(x, 1.0)]
-            y = self._conv(srcs, self.W[p + "conv_res0.weight"], rows, R, R, up=up, pro=L_PRO_SILU,
-                           epi=L_EPI_SCALE_SILU, cvec=cv)
+            if x3:
+                cs = self._split(srcs, L_PRO_SILU)                  # mp_silu(mp_cat(...)) once per element, as S8
+                y = self._conv([(cs, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, up=up,
+                               epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True)
+                self._free(cs)
+            else:
+                y = self._conv(srcs, self.W[p + "conv_res0.weight"], rows, R, R, up=up, pro=L_PRO_SILU,
+                               epi=L_EPI_SCALE_SILU, cvec=cv)
             if has_skip_conv:
                 xs = self._conv(srcs, self.W[p + "conv_skip.weight"], rows, R, R, up=up)
                 res, res_up = xs, 0
@@ -319,7 +357,7 @@ class Engine:
                 assert skip is None
                 xs, res, res_up = None, x, up
             out = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
-                             res_up=res_up, ta=ta, tb=tb, clip=clip_res)
+                             res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1)
             self._free(y)
             self._free(xs)
         self._tap(p + "res", out)
@@ -387,7 +425,12 @@ class Engine:
         x = x_in
         for b in spec.enc:
             if b.kind == "conv":
-                nx = self._conv([(x, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res)
+                if self.x3:
+                    xs8 = self._split([(x, 1.0)], 0)
+                    nx = self._conv([(xs8, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res, prec=1)
+                    self._free(xs8)
+                else:
+                    nx = self._conv([(x, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res)
                 self._tap(f"{prefix}enc.{b.name}.out", nx)
                 self._free(x)
             else:
@@ -502,7 +545,7 @@ class Engine:
             segs = [(io["src"], 0, 3 if cfg.warp_depth_coor else src_c, src_c, 1, 0)]
             if cfg.warp_depth_coor:
                 segs.append((sgrid, 1, 128, 128, 1, 0))
-            xin = self._assemble(segs, rows_all, R, _round_up(spec.in_channels, 4), io["sigma"])
+            xin = self._assemble(segs, rows_all, R, _round_up(spec.in_channels, 8 if self.x3 else 4), io["sigma"])
             self._free(sgrid)
             sgrid = None
             cvec, _ = self._embedding("encoder.", spec, rows_all, io["sigma"], 1, 0.0 if cfg.no_time_enc else 1.0,
@@ -522,14 +565,19 @@ class Engine:
             if cfg.super_res:
                 assert has_cond, "super_res needs a conditioning image (:656)"
                 segs.append((io["cond"], 0, cfg.img_channels, cfg.img_channels, 1, 0))
-            xin = self._assemble(segs, B, R, _round_up(spec.in_channels, 4), io["sigma"])
+            xin = self._assemble(segs, B, R, _round_up(spec.in_channels, 8 if self.x3 else 4), io["sigma"])
             self._free(dgrid)
             dgrid = None
             label_dim = cfg.target_label_dim
             cvec, _ = self._embedding("unet.", spec, B, io["sigma"], rm, 1.0, io["geometry"], label_dim)
             n_zero = float(self.nsrc) if (mode == "uncond") else 0.0
             last, _ = self._run_unet("unet.", spec, B, xin, cvec, feats if mode != "uncond" else None, False, n_zero)
-            F = self._conv([(last, 1.0)], self.W["unet.out_conv.weight"], B, R, R)
+            if self.x3:
+                ls8 = self._split([(last, 1.0)], 0)
+                F = self._conv([(ls8, 1.0)], self.W["unet.out_conv.weight"], B, R, R, prec=1)
+                self._free(ls8)
+            else:
+                F = self._conv([(last, 1.0)], self.W["unet.out_conv.weight"], B, R, R)
             self._free(last)
             self._free(cvec)
             self._call("vh_precond_out", L.PrecondOutArgs(x=io["x"].ptr, row_mul=rm, f=F.ptr, fc=F.shape[-1], sigma=io["sigma"].ptr,

@@ -44,8 +44,11 @@ class NVPrecond(torch.nn.Module):
     def __init__(self, img_resolution, img_channels, source_label_dim, target_label_dim,
                  use_fp16=True, sigma_data=0.5, logvar_channels=128, super_res=False, no_time_enc=None,
                  depth_input=False, warp_depth_coor=False, uncond=None, noisy_sr=0.25,
-                 dual_source=True, **unet_kwargs):
+                 dual_source=True, precision=None, **unet_kwargs):
         super().__init__()
+        import os
+        if precision is None:
+            precision = os.environ.get("VIVID_PRECISION", "fp32")
         allowed = {"model_channels", "channel_mult", "num_blocks", "attn_resolutions", "extra_attn",
                    "label_balance", "concat_balance", "res_balance", "attn_balance", "clip_act", "dropout",
                    "epipolar_attention_bias", "channel_mult_noise", "channel_mult_emb", "resample_filter"}
@@ -98,18 +101,19 @@ class NVPrecond(torch.nn.Module):
             else:
                 node.register_parameter(leaf, torch.nn.Parameter(torch.randn(shape)))
         self.requires_grad_(False)
-        self._engine = Engine(self.cfg, dual_source=dual_source)
+        self.precision = precision
+        self._engine = Engine(self.cfg, dual_source=dual_source, precision=precision)
         self._prepared_fp = None
         self._inject_cache = None
 
     @classmethod
-    def from_config(cls, cfg: NetConfig, dual_source: bool = True) -> "NVPrecond":
+    def from_config(cls, cfg: NetConfig, dual_source: bool = True, precision=None) -> "NVPrecond":
         return cls(img_resolution=cfg.img_resolution, img_channels=cfg.img_channels,
                    source_label_dim=cfg.source_label_dim, target_label_dim=cfg.target_label_dim,
                    use_fp16=cfg.use_fp16, sigma_data=cfg.sigma_data, logvar_channels=cfg.logvar_channels,
                    super_res=cfg.super_res, no_time_enc=cfg.no_time_enc, depth_input=cfg.depth_input,
                    warp_depth_coor=cfg.warp_depth_coor, uncond=cfg.uncond, noisy_sr=cfg.noisy_sr,
-                   dual_source=dual_source, model_channels=cfg.model_channels, channel_mult=cfg.channel_mult,
+                   dual_source=dual_source, precision=precision, model_channels=cfg.model_channels, channel_mult=cfg.channel_mult,
                    num_blocks=cfg.num_blocks, attn_resolutions=cfg.attn_resolutions, extra_attn=cfg.extra_attn,
                    label_balance=cfg.label_balance, concat_balance=cfg.concat_balance,
                    res_balance=cfg.res_balance, attn_balance=cfg.attn_balance, clip_act=cfg.clip_act)
