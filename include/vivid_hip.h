@@ -182,6 +182,14 @@ typedef struct {
 } vh_attention_args;
 int vh_attention(vh_ctx* ctx, const vh_attention_args* a);
 
+/* bf16x3 variants of the two attention entry points (same argument structs): the split kernel writes
+ * K in the S8 layout [b][head][klp][D/8][hi x8|lo x8] and V transposed, [b][head][D][hl][klp] bf16 with key
+ * positions permuted inside each group of 16 (bits 2 and 3 swapped), klp = kl rounded up to 64; both
+ * buffers must hold b*heads*klp*D*4 bytes.  vh_attention_x3 evaluates every product as
+ * hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 softmax statistics. */
+int vh_qkv_split_x3(vh_ctx* ctx, const vh_qkv_split_args* a);
+int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* a);
+
 /* ---- K13 + K4 + K7 + K5: noise/pose embedding -----------------------------
  * emb = mp_silu(mp_sum(emb_noise(fourier(c_noise)), emb_label(geometry), t)) :388-391,:485-488
  * with c_noise = ln(sigma)/4 * time_scale (:638,:667).  sigma row for output row r is

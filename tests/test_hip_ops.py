@@ -1,0 +1,286 @@
+"""GPU: each C-ABI op against a plain PyTorch fp32 statement of the same reference op
+(oracle functions from oracle/vivid_ref.py where one exists), called through libvivid_hip.so.
+
+Tolerances: fp32 kernels 2e-5 rel-L2 (summation order, hardware exp2/rcp); bf16x3 kernels 1e-4
+(hi/lo split drops ~2^-16 of each product) — both far inside north_star's 1e-3."""
+import math
+
+import pytest
+import torch
+
+from oracle import vivid_ref as R
+from tests.conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+LOG2E = 1.4426950408889634
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vivid_amd import _lib
+    return _lib.Context(torch.cuda.current_stream().cuda_stream)
+
+
+def _prep(ctx, w, taps, gain=1.0, split=0):
+    from vivid_amd import _lib as L
+    cout, cin = w.shape[0], w.shape[1]
+    cin_pad = (cin + (31 if split else 3)) // (32 if split else 4) * (32 if split else 4)
+    k_pad = (taps * cin_pad + 31) // 32 * 32
+    wt = torch.zeros(k_pad // 4 * cout * 4, device="cuda")
+    ctx.call("vh_prep_weight", L.PrepWeightArgs(w=w.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=k_pad,
+                                                gain_ptr=None, gain_value=gain, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=split))
+    return wt, cin_pad, k_pad
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _s8_decode(buf, shape):
+    """S8 (bf16 hi/lo) buffer -> fp32 tensor [..., C]."""
+    n = 1
+    for s in shape:
+        n *= s
+    raw = buf.view(torch.int16)[: n * 2].view(*shape[:-1], shape[-1] // 8, 2, 8)
+    f = (raw.to(torch.int32) << 16).view(torch.float32)
+    return (f[..., 0, :] + f[..., 1, :]).reshape(shape)
+
+
+@pytest.mark.parametrize("rows,h,w,cin,cout,taps", [(2, 8, 8, 64, 96, 9), (1, 16, 12, 36, 128, 9), (3, 4, 4, 128, 64, 1),
+                                                   (2, 2, 2, 260, 200, 9), (1, 33, 7, 8, 3, 9)])
+def test_conv_store_fp32(ctx, rows, h, w, cin, cout, taps):
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(rows * 100 + cin)
+    x = torch.randn(rows, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, *([3, 3] if taps == 9 else [1, 1]), generator=g)
+    ref = R.mp_conv(x, wgt, gain=0.7)
+    xd, wd = _nhwc(x).cuda(), wgt.cuda()
+    wt, cin_pad, k_pad = _prep(ctx, wd, taps, gain=0.7)
+    out = torch.empty(rows, h, w, cout, device="cuda")
+    ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=cout, out=out.data_ptr(),
+                                  out_s8=None, out_s8_c=0, prec=0, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), _nhwc(ref)) < 2e-5
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
+    """Decoder conv_res0: mp_silu(mp_cat(up(x), skip)) -> conv3x3 -> mp_silu(y*c)   (models.py:167,174-176,403)."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(7)
+    rows, h, w, ca, cb, cout = 2, 8, 8, 64, 32, 64
+    x = torch.randn(rows, ca, h, w, generator=g)            # already at output resolution for the concat case
+    skip = torch.randn(rows, cb, h, w, generator=g)
+    wgt = torch.randn(cout, ca + cb, 3, 3, generator=g)
+    c = torch.randn(rows, cout, generator=g) * 0.3 + 1
+    cat = R.mp_cat(x, skip, t=0.5)
+    ref = R.mp_silu(R.mp_conv(R.mp_silu(cat), wgt) * c[:, :, None, None])
+    t = 0.5
+    Cc = math.sqrt((ca + cb) / ((1 - t) ** 2 + t ** 2))
+    wa, wb = Cc / math.sqrt(ca) * (1 - t), Cc / math.sqrt(cb) * t
+    xd, sd, cd = _nhwc(x).cuda(), _nhwc(skip).cuda(), c.cuda()
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=prec)
+    out = torch.empty(rows, h, w, cout, device="cuda")
+    if prec == 0:
+        ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=sd.data_ptr(), c0=ca, c1=cb, scale0=wa, scale1=wb, rows=rows, h=h, w=w,
+                                      up=0, taps=9, pro=1, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=cout, out=out.data_ptr(),
+                                      out_s8=None, out_s8_c=0, prec=0, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0, ta=0, tb=0, clip=0))
+        got = out
+    else:
+        s8 = torch.empty(rows * h * w * cin_pad, device="cuda")
+        ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=sd.data_ptr(), c0=ca, c1=cb, scale0=wa, scale1=wb, pro=1,
+                                        npix=rows * h * w, c_pad=cin_pad, out=s8.data_ptr()))
+        o8 = torch.empty(rows * h * w * cout, device="cuda")
+        ctx.call("vh_conv", L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin_pad, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
+                                      up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=cout, out=None,
+                                      out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0,
+                                      ta=0, tb=0, clip=0))
+        torch.cuda.synchronize()
+        got = _s8_decode(o8, (rows, h, w, cout))
+    torch.cuda.synchronize()
+    assert rel_l2(got.cpu(), _nhwc(ref)) < (2e-5 if prec == 0 else 1e-4)
+
+
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv_up_mpsum_clip(ctx, prec):
+    """'up' block: conv_res1 epilogue mp_sum(resample_up(x), y, 0.3) with clip   (models.py:60-61,184,204-205)."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    rows, h, w, c = 2, 8, 8, 64
+    xlow = torch.randn(rows, c, h // 2, w // 2, generator=g) * 3
+    y_in = torch.randn(rows, c, h, w, generator=g)
+    wgt = torch.randn(c, c, 3, 3, generator=g)
+    ref = R.mp_sum(R.resample(xlow, "up"), R.mp_conv(y_in, wgt), t=0.3).clip(-2.0, 2.0)
+    n = math.sqrt(0.7 ** 2 + 0.3 ** 2)
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=prec)
+    yd, rd = _nhwc(y_in).cuda(), _nhwc(xlow).cuda()
+    src = yd
+    if prec == 1:
+        src = torch.empty(rows * h * w * cin_pad, device="cuda")
+        ctx.call("vh_split", L.SplitArgs(src0=yd.data_ptr(), src1=None, c0=c, c1=0, scale0=1.0, scale1=1.0, pro=0,
+                                        npix=rows * h * w, c_pad=cin_pad, out=src.data_ptr()))
+    out = torch.empty(rows, h, w, c, device="cuda")
+    ctx.call("vh_conv", L.ConvArgs(src0=src.data_ptr(), src1=None, c0=cin_pad if prec else c, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
+                                  up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=c, out=out.data_ptr(),
+                                  out_s8=None, out_s8_c=0, prec=prec, epi=2, cvec=None, cvec_ld=0, res=rd.data_ptr(), res_up=1,
+                                  ta=0.7 / n, tb=0.3 / n, clip=2.0))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), _nhwc(ref)) < (2e-5 if prec == 0 else 1e-4)
+
+
+@pytest.mark.parametrize("pool", [0, 1])
+def test_pixnorm_and_s8(ctx, pool):
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    rows, h, w, c = 2, 4, 6, 96
+    x = torch.randn(rows, c, h * (2 if pool else 1), w * (2 if pool else 1), generator=g) * 2
+    ref = R.normalize(R.resample(x, "down") if pool else x, dim=1)
+    xd = _nhwc(x).cuda()
+    out = torch.empty(rows, h, w, c, device="cuda")
+    s8 = torch.empty(rows * h * w * c, device="cuda")
+    ctx.call("vh_pixnorm", L.PixnormArgs(inp=xd.data_ptr(), out=out.data_ptr(), rows=rows, h=h, w=w, c=c, pool=pool, norm=1, out_s8=s8.data_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), _nhwc(ref)) < 1e-6
+    assert rel_l2(_s8_decode(s8, (rows, h, w, c)).cpu(), _nhwc(R.mp_silu(ref))) < 2e-5
+
+
+ATT_CASES = [(1, 1, 4, 8, 64, 0), (2, 2, 4, 12, 64, 0), (1, 3, 16, 32, 64, 0), (2, 1, 16, 48, 32, 0), (1, 2, 64, 192, 64, 0),
+             (1, 2, 256, 768, 64, 0), (1, 1, 300, 300, 32, 0), (2, 2, 64, 64, 64, 128), (1, 4, 1024, 1024, 32, 0),
+             (1, 1, 130, 200, 64, 5)]
+
+
+@pytest.mark.parametrize("x3", [0, 1])
+@pytest.mark.parametrize("b,heads,s,kl,d,nz", ATT_CASES)
+def test_qkv_split_and_attention(ctx, x3, b, heads, s, kl, d, nz):
+    """normalize(dim=2) of the [B,h,D,3,S] view + SDPA (models.py:192-199; cross keys appended as :283-297)."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(b * 1000 + s + kl + d)
+    C = heads * d
+    qkv = torch.randn(b, C * 3, s, generator=g) * 1.7          # NCHW-flattened 1x1-conv output, channel = (h*D+d)*3+j
+    nck = kl - s                                               # cross keys
+    kv = torch.randn(b, C * 2, max(nck, 1), generator=g)
+    qn = R.normalize(qkv.view(b, heads, d, 3, s), dim=2)
+    q, k, v = qn.unbind(3)
+    if nck > 0:
+        kc, vc = R.normalize(kv.view(b, heads, d, 2, nck), dim=2).unbind(3)
+        k, v = torch.cat([k, kc], dim=3), torch.cat([v, vc], dim=3)
+    if nz:                                                     # zero keys/values (uncond guidance, :727-736)
+        k = torch.cat([k, torch.zeros(b, heads, d, nz)], dim=3)
+        v = torch.cat([v, torch.zeros(b, heads, d, nz)], dim=3)
+    ref = torch.nn.functional.scaled_dot_product_attention(q.transpose(-1, -2), k.transpose(-1, -2), v.transpose(-1, -2))
+    ref = ref.transpose(-1, -2).reshape(b, C, s)               # channel = h*D + d
+    qkv_d = qkv.permute(0, 2, 1).contiguous().cuda()           # [b, s, 3C]
+    kv_d = kv.permute(0, 2, 1).contiguous().cuda()
+    klp = (kl + 63) // 64 * 64
+    Q = torch.full((b * heads * s * d,), float("nan"), device="cuda")
+    K = torch.full((b * heads * klp * d,), float("nan"), device="cuda")    # poison: pads must never leak
+    V = torch.full((b * heads * klp * d,), float("nan"), device="cuda")
+    out = torch.empty(b, s, C, device="cuda")
+    sp, at = ("vh_qkv_split_x3", "vh_attention_x3") if x3 else ("vh_qkv_split", "vh_attention")
+    ctx.call(sp, L.QkvSplitArgs(inp=qkv_d.data_ptr(), rows=b, s=s, heads=heads, d=d, nj=3, rows_per_b=1, koff=0, kl=kl,
+                                qscale=LOG2E / math.sqrt(d), q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr()))
+    if nck > 0:
+        assert nck % 1 == 0
+        ctx.call(sp, L.QkvSplitArgs(inp=kv_d.data_ptr(), rows=b, s=nck, heads=heads, d=d, nj=2, rows_per_b=1, koff=s, kl=kl,
+                                    qscale=1.0, q=None, k=K.data_ptr(), v=V.data_ptr()))
+    ctx.call(at, L.AttentionArgs(q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), b=b, heads=heads, s=s, kl=kl, d=d,
+                                 n_zero_keys=float(nz), out=out.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_l2(out.cpu(), ref.permute(0, 2, 1)) < (1e-4 if x3 else 2e-5)
+
+
+def test_attention_softmax_rescale_branch(ctx):
+    """Force the running-max update late in the key sequence: one key matches one query far better
+    than everything before it (cdna guide rule 26: a rare data-dependent branch needs its own test)."""
+    from vivid_amd import _lib as L
+    b, heads, s, kl, d = 1, 1, 64, 512, 64
+    g = torch.Generator().manual_seed(99)
+    q = torch.randn(b, heads, s, d, generator=g) * 0.05
+    k = torch.randn(b, heads, kl, d, generator=g) * 0.05
+    v = torch.randn(b, heads, kl, d, generator=g)
+    q[0, 0, 5] = 3.0 * torch.ones(d)
+    k[0, 0, 400] = 3.0 * torch.ones(d)          # logit 9*64/8 = 72 >> everything else, at key 400
+    k[0, 0, 130] = 1.0 * torch.ones(d)
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+    for x3 in (0, 1):
+        klp = kl
+        Qd = (q * (LOG2E / math.sqrt(d))).contiguous().cuda()
+        kd, vd = k.cuda(), v.cuda()
+        out = torch.empty(b, s, heads * d, device="cuda")
+        if x3 == 0:
+            ctx.call("vh_attention", L.AttentionArgs(q=Qd.data_ptr(), k=kd.data_ptr(), v=vd.data_ptr(), b=b, heads=heads,
+                                                     s=s, kl=kl, d=d, n_zero_keys=0.0, out=out.data_ptr()))
+        else:
+            # build the x3 operand formats through the split kernel from an un-normalised source is not possible
+            # (it normalises), so lay them out here: K as S8, V transposed with the bit-2/3 key permutation.
+            def split(t):
+                hi = t.to(torch.bfloat16).to(torch.float32)
+                lo = (t - hi).to(torch.bfloat16)
+                return t.to(torch.bfloat16), lo
+            kh, kl_ = split(k)
+            K8 = torch.stack([kh.view(b, heads, klp, d // 8, 8), kl_.view(b, heads, klp, d // 8, 8)], dim=4).contiguous().cuda()
+            vh, vl = split(v)
+            pos = torch.arange(klp)
+            key_at_pos = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1)
+            VT = torch.stack([vh[:, :, key_at_pos].transpose(-1, -2), vl[:, :, key_at_pos].transpose(-1, -2)], dim=3).contiguous().cuda()
+            ctx.call("vh_attention_x3", L.AttentionArgs(q=Qd.data_ptr(), k=K8.data_ptr(), v=VT.data_ptr(), b=b, heads=heads,
+                                                        s=s, kl=kl, d=d, n_zero_keys=0.0, out=out.data_ptr()))
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu().view(b, s, heads, d).permute(0, 2, 1, 3), ref) < (1e-4 if x3 else 2e-5), x3
+
+
+def test_embed_and_linear(ctx):
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    rows, cnoise, cemb, ld = 3, 64, 256, 40
+    sigma = torch.tensor([80.0, 1.3, 0.02])
+    geo = torch.randn(rows, ld, generator=g)
+    freqs, phases = 2 * math.pi * torch.randn(cnoise, generator=g), 2 * math.pi * torch.rand(cnoise, generator=g)
+    wn, wl = torch.randn(cemb, cnoise, generator=g), torch.randn(cemb, ld, generator=g)
+    emb = R.mp_silu(R.mp_sum(R.mp_conv(R.mp_fourier(sigma.log() / 4, freqs, phases), wn), R.mp_conv(geo, wl), t=0.5))
+    wlin = torch.randn(200, cemb, generator=g)
+    ref_c = R.mp_conv(emb, wlin, gain=0.37) + 1
+    wtn, _, kpn = _prep(ctx, wn.cuda(), 1)
+    wtl, _, kpl = _prep(ctx, wl.cuda(), 1)
+    wtc, _, kpc = _prep(ctx, wlin.cuda(), 1, gain=0.37)
+    out = torch.empty(rows, cemb, device="cuda")
+    sd, gd, fd, pd = sigma.cuda(), geo.cuda(), freqs.cuda(), phases.cuda()
+    ctx.call("vh_embed", L.EmbedArgs(sigma=sd.data_ptr(), sigma_stride=1, time_scale=1.0, geometry=gd.data_ptr(), label_dim=ld,
+                                    geometry_scale=1.0, freqs=fd.data_ptr(), phases=pd.data_ptr(), cnoise=cnoise, w_noise=wtn.data_ptr(),
+                                    w_noise_kpad=kpn, w_label=wtl.data_ptr(), w_label_kpad=kpl, label_balance=0.5, rows=rows, cemb=cemb,
+                                    raw=0, emb=out.data_ptr()))
+    cv = torch.empty(rows, 200, device="cuda")
+    ctx.call("vh_linear", L.LinearArgs(emb=out.data_ptr(), rows=rows, cemb=cemb, wt=wtc.data_ptr(), k_pad=kpc, cols=200, bias=1.0, out=cv.data_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), emb) < 2e-5
+    assert rel_l2(cv.cpu(), ref_c) < 2e-5
+
+
+def test_sampler_step_euler_heun_guided(ctx):
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(8)
+    B, n = 3, 3 * 8 * 8
+    x = torch.randn(2 * B, n, generator=g)
+    D, Dr = torch.randn(B, n, generator=g), torch.randn(B, n, generator=g)
+    t_hat, t_next, gd = 2.5, 1.1, 1.5
+    Dg = Dr.lerp(D, gd)
+    d_cur = (x[::2] - Dg) / t_hat
+    xn = x[::2] + (t_next - t_hat) * d_cur
+    xd, Dd, Drd = x.cuda(), D.cuda(), Dr.cuda()
+    dc, xo = torch.empty(B, n, device="cuda"), torch.empty(2 * B, n, device="cuda")
+    ctx.call("vh_sampler_step", L.SamplerStepArgs(x_hat=xd.data_ptr(), x_probe=None, d_cond=Dd.data_ptr(), d_ref=Drd.data_ptr(), guidance=gd,
+                                                  d_cur=dc.data_ptr(), t_hat=t_hat, t_next=t_next, rows=B, row_mul=2, row_elems=n, x_next=xo.data_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(xo.cpu()[::2], xn) < 1e-6 and torch.equal(xo[::2], xo[1::2])
+    D2 = torch.randn(B, n, generator=g)
+    dp = (xn - D2) / t_next
+    x2 = x[::2] + (t_next - t_hat) * (0.5 * d_cur + 0.5 * dp)
+    xo2 = torch.empty(2 * B, n, device="cuda")
+    D2d = D2.cuda()
+    ctx.call("vh_sampler_step", L.SamplerStepArgs(x_hat=xd.data_ptr(), x_probe=xo.data_ptr(), d_cond=D2d.data_ptr(), d_ref=None, guidance=1.0,
+                                                  d_cur=dc.data_ptr(), t_hat=t_hat, t_next=t_next, rows=B, row_mul=2, row_elems=n, x_next=xo2.data_ptr()))
+    torch.cuda.synchronize()
+    assert rel_l2(xo2.cpu()[::2], x2) < 1e-6

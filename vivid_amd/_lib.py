@@ -107,6 +107,7 @@ class SamplerStepArgs(C.Structure):
 OPS = {
     "vh_prep_weight": PrepWeightArgs, "vh_conv": ConvArgs, "vh_pixnorm": PixnormArgs, "vh_split": SplitArgs,
     "vh_qkv_split": QkvSplitArgs, "vh_attention": AttentionArgs, "vh_embed": EmbedArgs,
+    "vh_qkv_split_x3": QkvSplitArgs, "vh_attention_x3": AttentionArgs,
     "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
     "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs,
 }

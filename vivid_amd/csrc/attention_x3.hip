@@ -1,0 +1,365 @@
+// Flash-style attention on bf16 MFMA with fp32 emulated by a hi/lo split ("bf16x3"), gfx950.
+//
+// Same algorithm and call sites as attention.hip (F.scaled_dot_product_attention,
+// reference training/models.py:198,:305); every fp32 product a*b is evaluated as
+// a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+// (x = hi + lo, hi = bf16(x), lo = bf16(x - hi)); softmax statistics stay in fp32.
+//
+// Operand formats (written by qkv_split_x3_k below, so the hot loop only copies 16-byte units):
+//   Q   fp32 [bh][S][D], pre-scaled by log2(e)/sqrt(D); split to bf16 hi/lo in registers once.
+//   K   "S8": [bh][KLp][D/8][hi x8 | lo x8] bf16 (a key row is D*4 bytes).
+//   V^T [bh][D][hl][KLp] bf16, key positions permuted inside every group of 16
+//       (pos = key with bits 2 and 3 swapped) so that the 8 keys one lane half needs for a
+//       16-key MFMA step — the S^T accumulator row map — are one contiguous 16-byte unit.
+// One workgroup = NW waves x 32 queries of one (batch, head); K/V stream through LDS in 64-key
+// tiles, double-buffered, one barrier per tile.  S^T = K Q^T puts the query on the lane, P stays
+// in registers (accumulators -> bf16 pairs -> B operand of O^T += V^T P^T), as in attention.hip.
+// The running max is only raised (and O rescaled) when some query's max grew by more than 2^8
+// (fp32 accumulators: no precision is lost by the deferred scale).
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int KT = 64;
+constexpr float RESCALE_THR = 8.0f;
+
+struct AttnXK {
+    const float* q; const uint4* k; const uint4* vt; float* out;
+    int heads, s, kl, klp, c;
+    float n_zero;
+};
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// 8 floats -> bf16x8 hi and lo fragments
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+    unsigned h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = bf16_rn_bits(v[j]);
+        l[j] = bf16_rn_bits(v[j] - __uint_as_float(h[j] << 16));
+    }
+    uint4 hp = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    uint4 lp = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    hi = *reinterpret_cast<bf16x8*>(&hp);
+    lo = *reinterpret_cast<bf16x8*>(&lp);
+}
+
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
+    constexpr int NT = NW * 64;
+    constexpr int KU = D / 4;                 // 16-byte units per key row (hi+lo)       : 16 for D=64
+    constexpr int K_UNITS = KU * KT;          // units per K tile                        : 1024
+    constexpr int V_UNITS = D * 2 * (KT / 8); // units per V^T tile (D rows x {hi,lo} x 8): 1024
+    __shared__ uint4 sK[2][K_UNITS];          // [unit u = 2*chunk+hl][key ^ (u&7)]
+    __shared__ uint4 sV[2][V_UNITS];          // [d][slot ^ (d&15)], slot = hl*8 + key/8
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
+    const int bh = blockIdx.y;
+    const int b = bh / a.heads, hd = bh - b * a.heads;
+    const int q0 = blockIdx.x * (NW * 32) + wv * 32;
+    const int qrow = q0 + lr;
+
+    // ---- Q fragments -------------------------------------------------------------------------
+    bf16x8 qh[D / 16], ql[D / 16];
+    {
+        const float* Qb = a.q + ((size_t)bh * a.s + (qrow < a.s ? qrow : 0)) * D;
+#pragma unroll
+        for (int sl = 0; sl < D / 16; ++sl) {
+            float v[8];
+            const float4 p0 = *reinterpret_cast<const float4*>(Qb + sl * 16 + hh * 8);
+            const float4 p1 = *reinterpret_cast<const float4*>(Qb + sl * 16 + hh * 8 + 4);
+            v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+            if (qrow >= a.s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            split8(v, qh[sl], ql[sl]);
+        }
+    }
+
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float mrow = a.n_zero > 0.f ? 0.f : -1e30f;
+    float lsum = a.n_zero;
+
+    // ---- staging maps ---------------------------------------------------------------------------
+    constexpr int KPT = K_UNITS / NT, VPT = V_UNITS / NT;   // units per thread per tile
+    const uint4* Kb = a.k + (size_t)bh * a.klp * KU;
+    const uint4* Vb = a.vt + (size_t)bh * D * 2 * (a.klp / 8);
+    uint4 rk[KPT], rv[VPT];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = t + i * NT;
+            const int key = idx / KU, u = idx - key * KU;
+            rk[i] = Kb[(size_t)(k0 + key) * KU + u];            // klp is a multiple of KT: always in range
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = t + i * NT;
+            const int row = idx >> 3, ku = idx & 7;               // row = d*2 + hl
+            rv[i] = Vb[(size_t)row * (a.klp / 8) + (k0 >> 3) + ku];
+        }
+    };
+    auto store_tile = [&](int buf, int k0) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = t + i * NT;
+            const int key = idx / KU, u = idx - key * KU;
+            sK[buf][u * KT + (key ^ (u & 7))] = (k0 + key < a.kl) ? rk[i] : zero4;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = t + i * NT;
+            const int row = idx >> 3, ku = idx & 7;
+            const int d = row >> 1, hl = row & 1;
+            uint4 v = rv[i];
+            if (k0 + (ku >> 1) * 16 + 16 > a.kl) {                // the unit's 16-key group reaches past the end: zero invalid keys
+                unsigned short* e = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    // position j of the unit holds key (pos with bits 2,3 swapped); groups of 8 map to themselves
+                    const int pos = ku * 8 + j;
+                    const int key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+                    if (k0 + key >= a.kl) e[j] = 0;
+                }
+            }
+            sV[buf][d * 16 + ((hl * 8 + ku) ^ (d & 15))] = v;
+        }
+    };
+
+    const int ntiles = (a.kl + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0, 0);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        const int k0 = tile * KT;
+        if (tile + 1 < ntiles) load_tile(k0 + KT);
+        const bool tail = k0 + KT > a.kl;
+
+#pragma unroll
+        for (int ks = 0; ks < KT / 32; ++ks) {
+            // ---- S^T = K Q^T ---------------------------------------------------------------------
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const int key = ks * 32 + lr;
+#pragma unroll
+            for (int sl = 0; sl < D / 16; ++sl) {
+                const int uh = (sl * 2 + hh) * 2, ul = uh + 1;
+                const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&sK[buf][uh * KT + (key ^ (uh & 7))]);
+                const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(&sK[buf][ul * KT + (key ^ (ul & 7))]);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl_, qh[sl], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[sl], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[sl], sacc, 0, 0, 0);
+            }
+            // ---- online softmax ------------------------------------------------------------------
+            if (tail) {
+                const int kbase = k0 + ks * 32 + 4 * hh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kbase + (r & 3) + 8 * (r >> 2) >= a.kl) sacc[r] = -INFINITY;
+            }
+            float mx = sacc[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (__any(mx > mrow + RESCALE_THR)) {          // wave-uniform: raise the running max for every query
+                const float mnew = fmaxf(mrow, mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
+                lsum *= alpha;
+                mrow = mnew;
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+            }
+            float pv[16];
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pv[r] = __builtin_amdgcn_exp2f(sacc[r] - mrow);
+                rs += pv[r];
+            }
+            rs += __shfl_xor(rs, 32);
+            lsum += rs;
+            // ---- O^T += V^T P^T : k-step s2 uses accumulator registers 8*s2 .. 8*s2+7 ------------------
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl;
+                split8(&pv[8 * s2], ph, pl);
+                const int kuh = ks * 4 + s2 * 2 + hh;         // unit (8 permuted keys) inside the 64-key row
+#pragma unroll
+                for (int dt = 0; dt < D / 32; ++dt) {
+                    const int d = dt * 32 + lr;
+                    const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&sV[buf][d * 16 + (kuh ^ (d & 15))]);
+                    const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&sV[buf][d * 16 + ((8 + kuh) ^ (d & 15))]);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[dt], 0, 0, 0);
+                    oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (tile + 1 < ntiles) store_tile(buf ^ 1, k0 + KT);
+        __syncthreads();
+    }
+
+    if (qrow < a.s) {
+        const float inv = 1.0f / lsum;
+        float* op = a.out + ((size_t)b * a.s + qrow) * a.c + hd * D;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 o;
+                o.x = oacc[dt][4 * g + 0] * inv; o.y = oacc[dt][4 * g + 1] * inv;
+                o.z = oacc[dt][4 * g + 2] * inv; o.w = oacc[dt][4 * g + 3] * inv;
+                *reinterpret_cast<float4*>(op + dt * 32 + 8 * g + 4 * hh) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// q/k/v split + head norm writing the operand formats above (view/normalize/unbind of
+// training/models.py:192-194, :279-293; sequence concat :296-297 via koff).
+// One workgroup = one (row, head) x 64 consecutive pixels.
+struct SplitXK {
+    const float* in; int rows, s, heads, nj, rows_per_b, koff, kl, klp; float qscale;
+    float* q; unsigned short* k; unsigned short* vt;
+};
+
+__device__ __forceinline__ int perm16(int key) {      // swap bits 2 and 3
+    return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void qkv_split_x3_k(const SplitXK a) {
+    constexpr int PG = 256 / D;                  // pixels handled per pass
+    __shared__ unsigned short sv[D * 2 * 64];    // [d][hl][64 local positions]
+    const int t = threadIdx.x;
+    const int d = t % D, g = t / D;
+    const int ntile = (a.s + 63) / 64;
+    const int tileid = blockIdx.x % ntile;
+    const int rh = blockIdx.x / ntile;
+    const int head = rh % a.heads, row = rh / a.heads;
+    const int bb = row / a.rows_per_b, seg = row - bb * a.rows_per_b;
+    const size_t bhq = (size_t)bb * a.heads + head;
+    const int s0 = tileid * 64;
+    const int kbase = a.koff + seg * a.s;          // key index of pixel 0 of this row
+    // fast path: the tile maps onto whole 16-key groups of this row's key range (V^T transposed through LDS)
+    const bool fast = (a.s % 16 == 0) && (((kbase + s0) & 15) == 0);
+    const float rsd = rsqrtf((float)D);
+    for (int pp = g; pp < 64; pp += PG) {
+        const int s = s0 + pp;
+        const bool ok = s < a.s;
+        const float* in = a.in + (((size_t)row * a.s + (ok ? s : 0)) * a.heads * D + (size_t)head * D + d) * a.nj;
+        for (int j = 0; j < a.nj; ++j) {
+            const float v = ok ? in[j] : 0.f;
+            float ss = v * v;
+#pragma unroll
+            for (int o = D / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+            const float y = v / (1e-4f + sqrtf(ss) * rsd);
+            const bool is_q = (a.nj == 3 && j == 0);
+            const bool is_k = (a.nj == 3) ? (j == 1) : (j == 0);
+            if (is_q) {
+                if (ok) a.q[(bhq * a.s + s) * D + d] = y * a.qscale;
+                continue;
+            }
+            const unsigned hi = bf16_rn_bits(y);
+            const unsigned lo = bf16_rn_bits(y - __uint_as_float(hi << 16));
+            const int key = kbase + s;
+            if (is_k) {
+                if (ok) {
+                    unsigned short* kp = a.k + ((bhq * a.klp + key) * D + (d & ~7)) * 2 + (d & 7);
+                    kp[0] = (unsigned short)hi;
+                    kp[8] = (unsigned short)lo;
+                }
+            } else if (fast) {
+                const int lp = perm16(pp);                       // tile start is 16-aligned: permute locally
+                sv[(d * 2 + 0) * 64 + lp] = (unsigned short)hi;
+                sv[(d * 2 + 1) * 64 + lp] = (unsigned short)lo;
+            } else if (ok) {
+                const size_t base = (bhq * D + d) * 2;
+                a.vt[(base + 0) * a.klp + perm16(key)] = (unsigned short)hi;
+                a.vt[(base + 1) * a.klp + perm16(key)] = (unsigned short)lo;
+            }
+        }
+    }
+    if (fast) {
+        __syncthreads();
+        // D*2 rows of 64 positions = 8 units of 16 B each
+        const int nvalid = min(64, a.s - s0);                   // multiple of 16 when fast (s % 16 == 0 then)
+        for (int idx = t; idx < D * 2 * 8; idx += 256) {
+            const int rowi = idx >> 3, ku = idx & 7;
+            if (ku * 8 >= nvalid) continue;
+            const uint4 v = *reinterpret_cast<const uint4*>(&sv[rowi * 64 + ku * 8]);
+            *reinterpret_cast<uint4*>(a.vt + (bhq * D * 2 + rowi) * a.klp + kbase + s0 + ku * 8) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int vh_qkv_split_x3(vh_ctx* ctx, const vh_qkv_split_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_qkv_split_x3: null args");
+    const vh_qkv_split_args a = *p;
+    VH_REQUIRE(a.in && a.k && a.v, "vh_qkv_split_x3: null tensor");
+    VH_REQUIRE(a.nj == 2 || (a.nj == 3 && a.q), "vh_qkv_split_x3: nj must be 2 or 3 (3 needs q)");
+    VH_REQUIRE(a.d == 32 || a.d == 64, "vh_qkv_split_x3: head dim %d unsupported (32 or 64)", a.d);
+    VH_REQUIRE(a.rows > 0 && a.s > 0 && a.heads > 0 && a.rows_per_b > 0 && a.rows % a.rows_per_b == 0, "vh_qkv_split_x3: bad geometry");
+    VH_REQUIRE(a.koff >= 0 && a.koff + a.rows_per_b * a.s <= a.kl, "vh_qkv_split_x3: keys do not fit");
+    VH_REQUIRE(vh_aligned16(a.k) && vh_aligned16(a.v), "vh_qkv_split_x3: pointers must be 16-byte aligned");
+    const int klp = (a.kl + KT - 1) / KT * KT;
+    SplitXK k{a.in, a.rows, a.s, a.heads, a.nj, a.rows_per_b, a.koff, a.kl, klp, a.qscale, a.q,
+              static_cast<unsigned short*>(static_cast<void*>(a.k)), static_cast<unsigned short*>(static_cast<void*>(a.v))};
+    const long long nblk = (long long)a.rows * a.heads * ((a.s + 63) / 64);
+    VH_REQUIRE(nblk < (1LL << 31), "vh_qkv_split_x3: grid too large");
+    const int d = a.d;
+    const double bytes = 8.0 * (double)a.rows * a.s * a.heads * a.d * a.nj;
+    return vh_dispatch(ctx, VH_TAG_QKVSPLIT, 0.0, bytes, [k, d, nblk](hipStream_t s) -> int {
+        if (d == 64) hipLaunchKernelGGL(qkv_split_x3_k<64>, dim3((unsigned)nblk), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL(qkv_split_x3_k<32>, dim3((unsigned)nblk), dim3(256), 0, s, k);
+        return vh_check_launch("qkv_split_x3_k");
+    });
+}
+
+extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_attention_x3: null args");
+    const vh_attention_args a = *p;
+    VH_REQUIRE(a.q && a.k && a.v && a.out, "vh_attention_x3: null tensor");
+    VH_REQUIRE(a.d == 32 || a.d == 64, "vh_attention_x3: head dim %d unsupported (32 or 64)", a.d);
+    VH_REQUIRE(a.b > 0 && a.heads > 0 && a.s > 0 && a.kl > 0, "vh_attention_x3: bad geometry");
+    VH_REQUIRE(vh_aligned16(a.q) && vh_aligned16(a.k) && vh_aligned16(a.v) && vh_aligned16(a.out), "vh_attention_x3: pointers must be 16-byte aligned");
+    VH_REQUIRE((long long)a.b * a.heads < 65536, "vh_attention_x3: b*heads too large for grid.y");
+    VH_REQUIRE(a.n_zero_keys >= 0.f, "vh_attention_x3: negative n_zero_keys");
+    const int klp = (a.kl + KT - 1) / KT * KT;
+    AttnXK k{a.q, static_cast<const uint4*>(static_cast<const void*>(a.k)), static_cast<const uint4*>(static_cast<const void*>(a.v)),
+             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys};
+    const int d = a.d;
+    const int nw = a.s > 128 ? 8 : 4;
+    const dim3 grid((a.s + nw * 32 - 1) / (nw * 32), a.b * a.heads);
+    const double bhd = (double)a.b * a.heads;
+    const double flops = 4.0 * bhd * a.s * a.kl * a.d;
+    const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);
+    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, grid](hipStream_t s) -> int {
+        if (d == 64 && nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 8>), grid, dim3(512), 0, s, k);
+        else if (d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 4>), grid, dim3(256), 0, s, k);
+        else if (nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<32, 8>), grid, dim3(512), 0, s, k);
+        else hipLaunchKernelGGL((attn_fwd_bf16x3<32, 4>), grid, dim3(256), 0, s, k);
+        return vh_check_launch("attn_fwd_bf16x3");
+    });
+}

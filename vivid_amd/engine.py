@@ -369,20 +369,23 @@ class Engine:
             kl = S * (1 + self.nsrc) if use_feat else S
             nz = n_zero * S if (b.xattn and not use_feat) else 0.0
             qkv = self._conv([(out, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R)
+            ax3 = self.x3 and D in (32, 64)
+            klp = _round_up(kl, 64) if ax3 else kl            # bf16x3: K as S8, V transposed, keys padded to 64
+            split_op, attn_op = ("vh_qkv_split_x3", "vh_attention_x3") if ax3 else ("vh_qkv_split", "vh_attention")
             q = self._alloc(rows, b.heads, S, D)
-            k = self._alloc(rows, b.heads, kl, D)
-            v = self._alloc(rows, b.heads, kl, D)
-            self._call("vh_qkv_split", L.QkvSplitArgs(inp=qkv.ptr, rows=rows, s=S, heads=b.heads, d=D, nj=3, rows_per_b=1,
-                                                     koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
+            k = self._alloc(rows, b.heads, klp, D)
+            v = self._alloc(rows, b.heads, klp, D)
+            self._call(split_op, L.QkvSplitArgs(inp=qkv.ptr, rows=rows, s=S, heads=b.heads, d=D, nj=3, rows_per_b=1,
+                                                koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
             self._free(qkv)
             if use_feat:
                 kv = self._conv([(feat, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R)
-                self._call("vh_qkv_split", L.QkvSplitArgs(inp=kv.ptr, rows=rows * self.nsrc, s=S, heads=b.heads, d=D, nj=2,
-                                                         rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0, q=None, k=k.ptr, v=v.ptr))
+                self._call(split_op, L.QkvSplitArgs(inp=kv.ptr, rows=rows * self.nsrc, s=S, heads=b.heads, d=D, nj=2,
+                                                    rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0, q=None, k=k.ptr, v=v.ptr))
                 self._free(kv)
             att = self._alloc(rows, R, R, C)
-            self._call("vh_attention", L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
-                                                      n_zero_keys=nz, out=att.ptr), f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz}")
+            self._call(attn_op, L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
+                                                n_zero_keys=nz, out=att.ptr), f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz} x3={int(ax3)}")
             self._free(q); self._free(k); self._free(v)
             ta2, tb2 = self._mp_sum_coeffs(cfg.attn_balance)
             self._conv([(att, 1.0)], self.W[p + "attn_proj.weight"], rows, R, R, epi=L_EPI_MPSUM, res=out,

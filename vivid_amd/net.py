@@ -9,8 +9,10 @@ use it unchanged:
         return_logvar=False, return_features=False, inject_features=None)
 
 Differences, all deliberate:
-  * compute is fp32 on gfx950 MFMA (``use_fp16`` / ``force_fp32`` are accepted and
-    ignored; the reference's fp16 mode is outside the 1e-3 parity budget, SURVEY 7);
+  * arithmetic is fp32-grade on gfx950 MFMA: ``precision="bf16x3"`` (default; fp32 emulated by a bf16
+    hi/lo split, 3 MFMAs per product, fp32 accumulate, ~1e-5 rel-L2 per call) or ``precision="fp32"``
+    (exact fp32 MFMA, ~1e-6); ``use_fp16`` / ``force_fp32`` are accepted and ignored — the reference's
+    fp16 mode is outside the 1e-3 parity budget (SURVEY 7);
   * inference only (no autograd through the HIP path);
   * the reference selects dual-source vs single-source with a module global
     (``custom_litdata_loader.VANILLA_MODE``); here it is the ``dual_source`` argument;
@@ -48,7 +50,7 @@ class NVPrecond(torch.nn.Module):
         super().__init__()
         import os
         if precision is None:
-            precision = os.environ.get("VIVID_PRECISION", "fp32")
+            precision = os.environ.get("VIVID_PRECISION", "bf16x3")
         allowed = {"model_channels", "channel_mult", "num_blocks", "attn_resolutions", "extra_attn",
                    "label_balance", "concat_balance", "res_balance", "attn_balance", "clip_act", "dropout",
                    "epipolar_attention_bias", "channel_mult_noise", "channel_mult_emb", "resample_filter"}
