@@ -147,6 +147,7 @@ typedef struct {
     int pro;                               /* VH_PRO_* */
     long long npix; int c_pad;
     void* out;
+    void* out_raw;                         /* optional second S8 output without the prologue (conv_skip's input) */
 } vh_split_args;
 int vh_split(vh_ctx* ctx, const vh_split_args* a);
 
@@ -179,6 +180,7 @@ typedef struct {
     int b, heads, s, kl, d;   /* d = 32 or 64 */
     float n_zero_keys;
     float* out;
+    int out_s8;               /* vh_attention_x3 only: write `out` in the S8 (bf16 hi/lo) layout for a bf16x3 attn_proj */
 } vh_attention_args;
 int vh_attention(vh_ctx* ctx, const vh_attention_args* a);
 

@@ -45,7 +45,7 @@ class PixnormArgs(C.Structure):
 class SplitArgs(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
                 ("scale0", C.c_float), ("scale1", C.c_float), ("pro", C.c_int), ("npix", C.c_longlong),
-                ("c_pad", C.c_int), ("out", C.c_void_p)]
+                ("c_pad", C.c_int), ("out", C.c_void_p), ("out_raw", C.c_void_p)]
 
 
 class QkvSplitArgs(C.Structure):
@@ -57,7 +57,7 @@ class QkvSplitArgs(C.Structure):
 class AttentionArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("b", C.c_int),
                 ("heads", C.c_int), ("s", C.c_int), ("kl", C.c_int), ("d", C.c_int),
-                ("n_zero_keys", C.c_float), ("out", C.c_void_p)]
+                ("n_zero_keys", C.c_float), ("out", C.c_void_p), ("out_s8", C.c_int)]
 
 
 class EmbedArgs(C.Structure):

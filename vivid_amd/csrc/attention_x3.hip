@@ -30,6 +30,7 @@ struct AttnXK {
     const float* q; const uint4* k; const uint4* vt; float* out;
     int heads, s, kl, klp, c;
     float n_zero;
+    int out_s8;
 };
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float v) {
@@ -218,7 +219,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
         __syncthreads();
     }
 
-    if (qrow < a.s) {
+    if (qrow < a.s && a.out_s8) {
+        // S8 row of this query: channel hd*D + d; d = dt*32 + 8g + 4hh + (0..3) -> 8-byte pieces of a chunk's hi and lo halves
+        const float inv = 1.0f / lsum;
+        unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + (((size_t)b * a.s + qrow) * a.c + hd * D) * 2;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = oacc[dt][4 * g + j] * inv;
+                    h[j] = bf16_rn_bits(v);
+                    l[j] = bf16_rn_bits(v - __uint_as_float(h[j] << 16));
+                }
+                unsigned short* q8 = op + (dt * 32 + 8 * g) * 2 + 4 * hh;
+                *reinterpret_cast<uint2*>(q8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(q8 + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            }
+    } else if (qrow < a.s) {
         const float inv = 1.0f / lsum;
         float* op = a.out + ((size_t)b * a.s + qrow) * a.c + hd * D;
 #pragma unroll
@@ -348,7 +368,8 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     VH_REQUIRE(a.n_zero_keys >= 0.f, "vh_attention_x3: negative n_zero_keys");
     const int klp = (a.kl + KT - 1) / KT * KT;
     AttnXK k{a.q, static_cast<const uint4*>(static_cast<const void*>(a.k)), static_cast<const uint4*>(static_cast<const void*>(a.v)),
-             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys};
+             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys, a.out_s8};
+    VH_REQUIRE(!a.out_s8 || (a.heads * a.d) % 32 == 0, "vh_attention_x3: S8 output needs heads*d %% 32 == 0");
     const int d = a.d;
     const int nw = a.s > 128 ? 8 : 4;
     const dim3 grid((a.s + nw * 32 - 1) / (nw * 32), a.b * a.heads);

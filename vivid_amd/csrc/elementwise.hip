@@ -146,6 +146,14 @@ __global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total)
         v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
     }
     unsigned h[8], l[8];
+    if (a.out_raw) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) split_bf16(v[j] * sc, h[j], l[j]);
+        uint4* o = reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out_raw) + (size_t)i * 16);
+        o[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+        o[1] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    }
+    if (!a.out) return;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float e = v[j] * sc;
@@ -373,14 +381,14 @@ extern "C" int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* p) {
 extern "C" int vh_split(vh_ctx* ctx, const vh_split_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_split: null args");
     const vh_split_args a = *p;
-    VH_REQUIRE(a.src0 && a.out, "vh_split: null tensor");
+    VH_REQUIRE(a.src0 && (a.out || a.out_raw), "vh_split: null tensor");
     VH_REQUIRE(a.c0 > 0 && a.c0 % 8 == 0, "vh_split: c0 must be a positive multiple of 8 (got %d)", a.c0);
     VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 8 == 0) : a.c1 == 0, "vh_split: bad c1 %d", a.c1);
     VH_REQUIRE(a.c_pad % 32 == 0 && a.c_pad >= a.c0 + a.c1, "vh_split: c_pad %d must be a multiple of 32 >= %d", a.c_pad, a.c0 + a.c1);
     VH_REQUIRE(a.npix > 0 && (a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU), "vh_split: bad arguments");
-    VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.out), "vh_split: pointers must be 16-byte aligned");
+    VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.out) && vh_aligned16(a.out_raw), "vh_split: pointers must be 16-byte aligned");
     const long long total = a.npix * (a.c_pad / 8);
-    return vh_dispatch(ctx, VH_TAG_SPLIT, 0.0, 4.0 * (double)a.npix * ((double)a.c0 + a.c1 + a.c_pad), [a, total](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_SPLIT, 0.0, 4.0 * (double)a.npix * ((double)a.c0 + a.c1 + a.c_pad * ((a.out ? 1 : 0) + (a.out_raw ? 1 : 0))), [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(split_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("split_k");
     });

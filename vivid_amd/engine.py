@@ -122,6 +122,12 @@ class Engine:
         self.nsrc = 2 if dual_source else 1
         self.enc_spec: Optional[UNetSpec] = None if cfg.uncond else unet_spec(cfg, role="encoder")
         self.unet_spec: UNetSpec = unet_spec(cfg, role="unet")
+        if self.x3:
+            for sp in (self.enc_spec, self.unet_spec):
+                for blk in (sp.enc + sp.dec if sp is not None else []):
+                    if blk.cout % 32:
+                        raise ValueError(f"precision='bf16x3' needs channel counts that are multiples of 32 "
+                                         f"({blk.name} has {blk.cout}); use precision='fp32'")
         self.W: Dict[str, Weight] = {}
         self.embW: Dict[str, Tuple[torch.Tensor, Dict[str, int], int]] = {}
         self.bufs: Dict[str, torch.Tensor] = {}
@@ -191,7 +197,7 @@ class Engine:
     def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None):
         w = self._params[key]
         cout, cin = w.shape[0], w.shape[1]
-        split = 1 if (self.x3 and taps == 9) else 0
+        split = 1 if (self.x3 and w.ndim == 4) else 0      # 2-D (linear) weights feed embed_k/linear_k: never split
         cin_pad = _round_up(cin, 32 if split else 4)
         k_pad = _round_up(taps * cin_pad, 32)
         wt = torch.empty(k_pad // 4 * cout * 4, dtype=torch.float32, device=w.device)
@@ -216,7 +222,7 @@ class Engine:
             for k, shp in shapes.items():
                 if k.endswith("weight"):
                     taps = 9 if len(shp) == 4 and shp[-1] == 3 else 1
-                    cin_pad = _round_up(shp[1], 32 if (self.x3 and taps == 9) else 4)
+                    cin_pad = _round_up(shp[1], 32 if (self.x3 and len(shp) == 4) else 4)
                     self.W[k] = Weight(dummy, cin_pad, _round_up(taps * cin_pad, 32), shp[0], taps)
             self.embW = {}
             for prefix, spec in (("encoder.", self.enc_spec), ("unet.", self.unet_spec)):
@@ -258,12 +264,13 @@ class Engine:
 
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
               cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0,
-              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False) -> Buf:
-        """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8."""
+              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False):
+        """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8;
+        also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned."""
         out_s8 = None
-        if s8_only:
+        if s8_only or also_s8:
             out_s8 = self._alloc(rows, h, w, W.cout)
-        elif out is None:
+        if not s8_only and out is None:
             out = self._alloc(rows, h, w, W.cout)
         s0, sc0 = srcs[0]
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
@@ -276,20 +283,25 @@ class Engine:
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
                        res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip)
         self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}")
+        if also_s8:
+            return out, out_s8
         return out_s8 if s8_only else out
 
-    def _split(self, srcs: Sequence[Tuple[Buf, float]], pro: int) -> Buf:
-        """fp32 NHWC (1-2 sources, mp_cat weights) -> S8 at the sources' resolution, channels padded to 32."""
+    def _split(self, srcs: Sequence[Tuple[Buf, float]], pro: int, raw_too: bool = False):
+        """fp32 NHWC (1-2 sources, mp_cat weights) -> S8 at the sources' resolution, channels padded to 32.
+        pro = prologue of the main output; raw_too additionally returns the un-activated split (conv_skip's input)."""
         s0, sc0 = srcs[0]
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
         rows, h, w = s0.shape[:3]
         ctot = s0.shape[-1] + (s1.shape[-1] if s1 is not None else 0)
         cpad = _round_up(ctot, 32)
         out = self._alloc(rows, h, w, cpad)
+        raw = self._alloc(rows, h, w, cpad) if raw_too else None
         self._call("vh_split", L.SplitArgs(src0=s0.ptr, src1=s1.ptr if s1 is not None else None, c0=s0.shape[-1],
                                           c1=s1.shape[-1] if s1 is not None else 0, scale0=sc0, scale1=sc1, pro=pro,
-                                          npix=rows * h * w, c_pad=cpad, out=out.ptr), f"rows={rows} {h}x{w} c={ctot}")
-        return out
+                                          npix=rows * h * w, c_pad=cpad, out=out.ptr, out_raw=raw.ptr if raw is not None else None),
+                   f"rows={rows} {h}x{w} c={ctot} raw={int(raw_too)}")
+        return (out, raw) if raw_too else out
 
     def _mp_sum_coeffs(self, t: float):
         n = math.sqrt((1 - t) ** 2 + t ** 2)
@@ -298,9 +310,10 @@ class Engine:
     # ------------------------------------------------------------------ one block
     def _block(self, prefix: str, grp: str, b: BlockSpec, rows: int, x: Buf, skip: Optional[Buf],
                cvec_all: Buf, cols: Dict[str, int], total_cols: int,
-               feat: Optional[Buf], n_zero: float) -> Buf:
+               feat: Optional[Buf], feat_s8: Optional[Buf], n_zero: float, want_s8: bool = False):
         """Block.forward :165-206 / XAttnBlock.forward :251-315.  x is the block input (before
-        resampling); returns the block output.  Neither x nor skip is released here."""
+        resampling); returns (block output fp32, its S8 copy or None).  Neither x nor skip is released here.
+        In bf16x3 mode every conv reads an S8 (bf16 hi/lo) tensor written by the op that produced it."""
         cfg = self.cfg
         p = f"{prefix}{grp}.{b.name}."
         R = b.res
@@ -309,28 +322,38 @@ class Engine:
         clip = float(cfg.clip_act) if cfg.clip_act is not None else 0.0
         clip_res = 0.0 if b.heads else clip
         has_skip_conv = b.cin != b.cout
-        tmp: List[Buf] = []
-        x3 = self.x3 and b.cout % 32 == 0
+        x3 = self.x3 and b.cout % 32 == 0 and b.cin % 32 == 0
         P1 = 1 if x3 else 0
+        C = b.cout
+        D = C // b.heads if b.heads else 0
+        ax3 = x3 and D in (32, 64)                      # attention (and its 1x1 convs) on the bf16x3 path
+        out_s8 = None
+        res1_s8 = bool(b.heads) and ax3                 # conv_res1's result also feeds attn_qkv -> S8 copy
+        fin_s8 = want_s8 and x3 and not b.heads         # no attention: conv_res1's result is the block output
         if b.flavor == "enc":
-            xs = self._alloc(rows, R, R, b.cout) if x3 else None      # S8 of mp_silu(xn): conv_res0's input
+            xs = self._alloc(rows, R, R, C) if x3 else None      # S8 of mp_silu(xn): conv_res0's input
             xs_ptr = xs.ptr if xs is not None else None
             if b.resample == "down":
-                xn = self._alloc(rows, R, R, b.cout)
-                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=1, norm=1, out_s8=xs_ptr))
+                xn = self._alloc(rows, R, R, C)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=1, norm=1, out_s8=xs_ptr))
             elif has_skip_conv:
-                xn = self._conv([(x, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R)
-                self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1, out_s8=xs_ptr))
+                if x3:
+                    xr = self._split([(x, 1.0)], 0)
+                    xn = self._conv([(xr, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R, prec=1)
+                    self._free(xr)
+                else:
+                    xn = self._conv([(x, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=0, norm=1, out_s8=xs_ptr))
             else:
-                xn = self._alloc(rows, R, R, b.cout)
-                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=b.cout, pool=0, norm=1, out_s8=xs_ptr))
+                xn = self._alloc(rows, R, R, C)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=0, norm=1, out_s8=xs_ptr))
             if x3:
                 y = self._conv([(xs, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True)
                 self._free(xs)
             else:
                 y = self._conv([(xn, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, pro=L_PRO_SILU, epi=L_EPI_SCALE_SILU, cvec=cv)
-            out = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn,
-                             ta=ta, tb=tb, clip=clip_res, prec=P1)
+            r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn,
+                           ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
             self._free(y)
             self._free(xn)
         else:
@@ -342,8 +365,13 @@ class Engine:
                 srcs = [(x, Cc / math.sqrt(Na) * (1 - t)), (skip, Cc / math.sqrt(Nb) * t)]
             else:
                 srcs = [(x, 1.0)]
+            craw = None
             if x3:
-                cs = self._split(srcs, L_PRO_SILU)                  # mp_silu(mp_cat(...)) once per element, as S8
+                # mp_silu(mp_cat(...)) once per element as S8; the raw split is conv_skip's input
+                if has_skip_conv:
+                    cs, craw = self._split(srcs, L_PRO_SILU, raw_too=True)
+                else:
+                    cs = self._split(srcs, L_PRO_SILU)
                 y = self._conv([(cs, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, up=up,
                                epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True)
                 self._free(cs)
@@ -351,25 +379,36 @@ class Engine:
                 y = self._conv(srcs, self.W[p + "conv_res0.weight"], rows, R, R, up=up, pro=L_PRO_SILU,
                                epi=L_EPI_SCALE_SILU, cvec=cv)
             if has_skip_conv:
-                xs = self._conv(srcs, self.W[p + "conv_skip.weight"], rows, R, R, up=up)
-                res, res_up = xs, 0
+                if x3:
+                    xsk = self._conv([(craw, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R, up=up, prec=1)
+                    self._free(craw)
+                else:
+                    xsk = self._conv(srcs, self.W[p + "conv_skip.weight"], rows, R, R, up=up)
+                res, res_up = xsk, 0
             else:
                 assert skip is None
-                xs, res, res_up = None, x, up
-            out = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
-                             res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1)
+                xsk, res, res_up = None, x, up
+            r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
+                           res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
             self._free(y)
-            self._free(xs)
+            self._free(xsk)
+        if res1_s8 or fin_s8:
+            out, r_s8 = r
+        else:
+            out, r_s8 = r, None
+        if fin_s8:
+            out_s8 = r_s8
         self._tap(p + "res", out)
         if b.heads:
-            C = b.cout
-            D = C // b.heads
             S = R * R
             use_feat = b.xattn and feat is not None
             kl = S * (1 + self.nsrc) if use_feat else S
             nz = n_zero * S if (b.xattn and not use_feat) else 0.0
-            qkv = self._conv([(out, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R)
-            ax3 = self.x3 and D in (32, 64)
+            if ax3:
+                qkv = self._conv([(r_s8, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R, prec=1)
+                self._free(r_s8)
+            else:
+                qkv = self._conv([(out, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R)
             klp = _round_up(kl, 64) if ax3 else kl            # bf16x3: K as S8, V transposed, keys padded to 64
             split_op, attn_op = ("vh_qkv_split_x3", "vh_attention_x3") if ax3 else ("vh_qkv_split", "vh_attention")
             q = self._alloc(rows, b.heads, S, D)
@@ -379,20 +418,32 @@ class Engine:
                                                 koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
             self._free(qkv)
             if use_feat:
-                kv = self._conv([(feat, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R)
+                if ax3:
+                    fs, own = feat_s8, False
+                    if fs is None:
+                        fs, own = self._split([(feat, 1.0)], 0), True
+                    kv = self._conv([(fs, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R, prec=1)
+                    if own:
+                        self._free(fs)
+                else:
+                    kv = self._conv([(feat, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R)
                 self._call(split_op, L.QkvSplitArgs(inp=kv.ptr, rows=rows * self.nsrc, s=S, heads=b.heads, d=D, nj=2,
                                                     rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0, q=None, k=k.ptr, v=v.ptr))
                 self._free(kv)
             att = self._alloc(rows, R, R, C)
             self._call(attn_op, L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
-                                                n_zero_keys=nz, out=att.ptr), f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz} x3={int(ax3)}")
+                                                n_zero_keys=nz, out=att.ptr, out_s8=1 if ax3 else 0),
+                       f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz} x3={int(ax3)}")
             self._free(q); self._free(k); self._free(v)
             ta2, tb2 = self._mp_sum_coeffs(cfg.attn_balance)
-            self._conv([(att, 1.0)], self.W[p + "attn_proj.weight"], rows, R, R, epi=L_EPI_MPSUM, res=out,
-                       ta=ta2, tb=tb2, clip=clip, out=out)
+            emit = want_s8 and ax3
+            r2 = self._conv([(att, 1.0)], self.W[p + "attn_proj.weight"], rows, R, R, epi=L_EPI_MPSUM, res=out,
+                            ta=ta2, tb=tb2, clip=clip, out=out, prec=1 if ax3 else 0, also_s8=emit)
+            if emit:
+                out_s8 = r2[1]
             self._free(att)
         self._tap(p + "out", out)
-        return out
+        return out, out_s8
 
     # ------------------------------------------------------------------ embeddings
     def _embedding(self, prefix: str, spec: UNetSpec, rows: int, sigma: Buf, sigma_stride: int, time_scale: float,
@@ -419,13 +470,27 @@ class Engine:
 
     # ------------------------------------------------------------------ networks
     def _run_unet(self, prefix: str, spec: UNetSpec, rows: int, x_in: Buf, cvec: Buf,
-                  feats: Optional[List[Buf]], collect: bool, n_zero: float):
-        """Shared walk of UNetEncoder.forward (collect=True) and XAttnUNet.forward (feats given or zero)."""
+                  feats: Optional[List[Tuple[Buf, Optional[Buf]]]], collect: bool, n_zero: float):
+        """Shared walk of UNetEncoder.forward (collect=True) and XAttnUNet.forward (feats given or zero).
+        feats / the returned feature list hold (fp32 NHWC, S8 copy or None) pairs."""
         _, cols, total = self.embW[prefix]
         skips: List[Buf] = []
-        out_feats: List[Buf] = []
+        out_feats: List[Tuple[Buf, Optional[Buf]]] = []
         fi = 0
         x = x_in
+
+        def kept(buf):
+            return any(buf is f[0] for f in out_feats)
+
+        def next_feat(b):
+            nonlocal fi
+            f = (None, None)
+            if b.xattn:
+                if feats is not None:
+                    f = feats[fi]
+                fi += 1
+            return f
+
         for b in spec.enc:
             if b.kind == "conv":
                 if self.x3:
@@ -437,37 +502,29 @@ class Engine:
                 self._tap(f"{prefix}enc.{b.name}.out", nx)
                 self._free(x)
             else:
-                feat = None
-                if b.xattn and feats is not None:
-                    feat = feats[fi]
-                if b.xattn:
-                    fi += 1
-                nx = self._block(prefix, "enc", b, rows, x, None, cvec, cols, total, feat, n_zero)
+                f32, f8 = next_feat(b)
+                nx, nx8 = self._block(prefix, "enc", b, rows, x, None, cvec, cols, total, f32, f8, n_zero,
+                                      want_s8=collect and b.heads > 0)
                 if collect and b.heads > 0:
-                    out_feats.append(nx)
+                    out_feats.append((nx, nx8))
             skips.append(nx)
             x = nx
         for b in spec.dec:
             if not b.live:
                 break
             skip = skips.pop() if b.takes_skip else None
-            feat = None
-            if b.xattn and feats is not None:
-                feat = feats[fi]
-            if b.xattn:
-                fi += 1
-            nx = self._block(prefix, "dec", b, rows, x, skip, cvec, cols, total, feat, n_zero)
-            keep = {id(f) for f in out_feats}
+            f32, f8 = next_feat(b)
+            nx, nx8 = self._block(prefix, "dec", b, rows, x, skip, cvec, cols, total, f32, f8, n_zero,
+                                  want_s8=collect and b.heads > 0)
             for old in (x, skip):
-                if old is not None and id(old) not in keep and all(old is not s for s in skips):
+                if old is not None and not kept(old) and all(old is not s_ for s_ in skips):
                     self._free(old)
             if collect and b.heads > 0:
-                out_feats.append(nx)
+                out_feats.append((nx, nx8))
             x = nx
-        keep = {id(f) for f in out_feats}
-        for s in skips:                               # skips the trimmed encoder-decoder never consumed
-            if id(s) not in keep and s is not x:
-                self._free(s)
+        for s_ in skips:                              # skips the trimmed encoder-decoder never consumed
+            if not kept(s_) and s_ is not x:
+                self._free(s_)
         return x, out_feats
 
     # ------------------------------------------------------------------ program construction
@@ -521,10 +578,11 @@ class Engine:
                 io["cond"] = self._alloc(B, cfg.img_channels, R, R)
         if want_logvar:
             io["logvar"] = self._alloc(B)
-        feats: Optional[List[Buf]] = None
+        feats: Optional[List[Tuple[Buf, Optional[Buf]]]] = None
         if mode == "inject":
-            feats = [self._alloc(rows_all, r, r, c) for (c, r) in self._feature_shapes()]
-            io["features_in"] = feats
+            fin = [self._alloc(rows_all, r, r, c) for (c, r) in self._feature_shapes()]
+            io["features_in"] = fin
+            feats = [(f, None) for f in fin]
         if fill is not None:                  # debug (immediate) mode: inputs must be in place before ops run
             fill(Program(None, self._backing, io))
 
@@ -554,10 +612,10 @@ class Engine:
             cvec, _ = self._embedding("encoder.", spec, rows_all, io["sigma"], 1, 0.0 if cfg.no_time_enc else 1.0,
                                       io["geometry"], cfg.source_label_dim)
             last, feats = self._run_unet("encoder.", spec, rows_all, xin, cvec, None, True, 0.0)
-            if all(last is not f for f in feats):
+            if all(last is not f[0] for f in feats):
                 self._free(last)
             self._free(cvec)
-            io["features_out"] = feats
+            io["features_out"] = [f[0] for f in feats]
         self._free(sgrid)
 
         if need_unet:
