@@ -68,7 +68,7 @@ int vh_plan_destroy(vh_plan* plan);
  *   w_hat[o] = w[o] / (1e-4 + ||w[o]||_2 / sqrt(fan_in)) * gain / sqrt(fan_in)
  * written in the layout the GEMM kernels stage from:
  *   wt[k/4][o][k%4],  k = tap * cin_pad + ci,  tap = ky*3+kx (taps = 1 or 9),
- * zero-filled for ci >= cin and k >= taps*cin_pad up to k_pad (multiple of 32).
+ * zero-filled for ci >= cin; cin_pad is a multiple of 32 and k_pad == taps*cin_pad.
  * `gain` is read from device memory if gain_ptr != NULL (emb_gain / out_gain are
  * 0-d Parameters, :157,:345), else gain_value is used.
  * `dst_col0`/`dst_cols` place the block into a wider matrix (batched emb_linear). */
@@ -113,7 +113,9 @@ typedef struct {
     int up;
     int taps;                              /* 1 or 9 */
     int pro;
-    const float* wt; int cin_pad, k_pad;   /* from vh_prep_weight */
+    const float* wt; int cin_pad, k_pad;   /* from vh_prep_weight: cin_pad % 32 == 0, k_pad == taps*cin_pad */
+    const float* zeros; size_t zeros_bytes; /* a device buffer of zeros, >= cin_pad*4 + 64 bytes: out-of-image taps and pad
+                                              channels are read from it instead of being masked */
     int cout;
     float* out;                            /* [rows*h*w][cout] fp32; may be NULL if out_s8 is given */
     void* out_s8; int out_s8_c;            /* optional S8 copy of the result (cout % 32 == 0, out_s8_c == cout) */

@@ -25,12 +25,21 @@ def ctx():
 def _prep(ctx, w, taps, gain=1.0, split=0):
     from vivid_amd import _lib as L
     cout, cin = w.shape[0], w.shape[1]
-    cin_pad = (cin + (31 if split else 3)) // (32 if split else 4) * (32 if split else 4)
-    k_pad = (taps * cin_pad + 31) // 32 * 32
+    cin_pad = (cin + 31) // 32 * 32
+    k_pad = taps * cin_pad
     wt = torch.zeros(k_pad // 4 * cout * 4, device="cuda")
     ctx.call("vh_prep_weight", L.PrepWeightArgs(w=w.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=k_pad,
                                                 gain_ptr=None, gain_value=gain, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=split))
     return wt, cin_pad, k_pad
+
+
+_Z = {}
+
+
+def _zeros():
+    if "z" not in _Z:
+        _Z["z"] = torch.zeros(16384, device="cuda")
+    return _Z["z"].data_ptr()
 
 
 def _nhwc(x):
@@ -59,7 +68,7 @@ def test_conv_store_fp32(ctx, rows, h, w, cin, cout, taps):
     wt, cin_pad, k_pad = _prep(ctx, wd, taps, gain=0.7)
     out = torch.empty(rows, h, w, cout, device="cuda")
     ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
-                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=cout, out=out.data_ptr(),
+                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=out.data_ptr(),
                                   out_s8=None, out_s8_c=0, prec=0, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), _nhwc(ref)) < 2e-5
@@ -85,7 +94,7 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
     out = torch.empty(rows, h, w, cout, device="cuda")
     if prec == 0:
         ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=sd.data_ptr(), c0=ca, c1=cb, scale0=wa, scale1=wb, rows=rows, h=h, w=w,
-                                      up=0, taps=9, pro=1, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=cout, out=out.data_ptr(),
+                                      up=0, taps=9, pro=1, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=out.data_ptr(),
                                       out_s8=None, out_s8_c=0, prec=0, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0, ta=0, tb=0, clip=0))
         got = out
     else:
@@ -94,7 +103,7 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
                                         npix=rows * h * w, c_pad=cin_pad, out=s8.data_ptr()))
         o8 = torch.empty(rows * h * w * cout, device="cuda")
         ctx.call("vh_conv", L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin_pad, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
-                                      up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=cout, out=None,
+                                      up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=None,
                                       out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0,
                                       ta=0, tb=0, clip=0))
         torch.cuda.synchronize()
@@ -123,7 +132,7 @@ def test_conv_up_mpsum_clip(ctx, prec):
                                         npix=rows * h * w, c_pad=cin_pad, out=src.data_ptr()))
     out = torch.empty(rows, h, w, c, device="cuda")
     ctx.call("vh_conv", L.ConvArgs(src0=src.data_ptr(), src1=None, c0=cin_pad if prec else c, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
-                                  up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, cout=c, out=out.data_ptr(),
+                                  up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=c, out=out.data_ptr(),
                                   out_s8=None, out_s8_c=0, prec=prec, epi=2, cvec=None, cvec_ld=0, res=rd.data_ptr(), res_up=1,
                                   ta=0.7 / n, tb=0.3 / n, clip=2.0))
     torch.cuda.synchronize()

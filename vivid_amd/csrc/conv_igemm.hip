@@ -39,7 +39,7 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 32, K4 = BK / 4;
 
 struct ConvK {
-    const float* src0; const float* src1;
+    const float* src0; const float* src1; const float* zeros;
     int c0, c1; float scale0, scale1;
     int h, w, up, pro;
     const float4* wt; int cin_pad, k_pad, cout;
@@ -80,7 +80,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- staging maps -----------------------------------------------------
-    const int k4a = t & 7, ma = t >> 3;          // A: 8 k-groups x 32 pixels, 4 passes
+    // K runs tap-major: k = tap*cin_pad + c, cin_pad a multiple of BK, so a K-tile is 32 channels of ONE tap.
+    // Per tap each thread derives a base pointer for each of its 4 pixels (or the zero page when the tap falls
+    // outside the image); inside a tap a K-tile only adds its channel offset.  Out-of-image taps and pad
+    // channels read the zero page, so no select is needed after the load.
+    const int k4a = t & 7, ma = t >> 3;          // A: 8 16-byte units x 32 pixels, 4 passes
     const int Hs = a.up ? (a.h >> 1) : a.h, Ws = a.up ? (a.w >> 1) : a.w;
     int py[4], px[4], pbase[4];
     bool pv[4];
@@ -95,9 +99,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
         px[i] = rem - py[i] * a.w;
         pbase[i] = img * Hs * Ws;
     }
-    const int nb = t & 127, k4b = t >> 7;        // B: 128 columns x 2 k-groups, 4 passes
+    const int nb = t & 127, k4b = t >> 7;        // B: 128 columns x 2 units, 4 passes
     const bool nvalid = (n0 + nb) < a.cout;
-    const float4* wptr = a.wt + (size_t)k4b * a.cout + (nvalid ? (n0 + nb) : 0);
+    const float4* wp = a.wt + (size_t)k4b * a.cout + (nvalid ? (n0 + nb) : 0);
+    const size_t wstep = (size_t)2 * a.cout;     // float4 units between the passes of one K-tile
+    const size_t wtile = (size_t)K4 * a.cout;    // ... and between K-tiles
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -108,39 +114,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[4];
-    unsigned okm = 0;          // bit i: the i-th staged A chunk is inside the image / channel range
     float rsc = 1.f;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* p0[4];
+    const float* p1[4];
 
-    // Loads are unconditional (clamped to a valid address) and zeroed by a select afterwards, so the
-    // eight global loads of a K-tile issue back to back with no branches and stay in flight over the MFMAs.
-    auto load_tile = [&](int kt) {
-        const int k0 = kt * BK + k4a * 4;
-        const int tap = (TAPS == 1) ? (k0 >= a.cin_pad ? 1 : 0) : k0 / a.cin_pad;
-        const int ci = k0 - tap * a.cin_pad;
+    auto setup_tap = [&](int tap) {
         int dy = 0, dx = 0;
         if (TAPS == 9) {
             const int ty = tap / 3;
             dy = ty - 1;
             dx = tap - ty * 3 - 1;
         }
-        const bool first = ci < a.c0;
-        const float* sp = first ? a.src0 : a.src1;
-        const int cs = first ? a.c0 : a.c1;
-        int cc = first ? ci : ci - a.c0;
-        rsc = first ? a.scale0 : a.scale1;
-        bool chok = (tap < TAPS) && (first || (a.src1 != nullptr && cc < a.c1));
-        if (!chok) { sp = a.src0; cc = 0; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = py[i] + dy, xx = px[i] + dx;
-            const bool ok = pv[i] && chok && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
-            const size_t pix = ok ? (size_t)(pbase[i] + (yy >> a.up) * Ws + (xx >> a.up)) : 0;
-            ra[i] = *reinterpret_cast<const float4*>(sp + pix * (chok ? cs : 0) + cc);
-            okm = ok ? (okm | (1u << i)) : (okm & ~(1u << i));
+            const bool ok = pv[i] && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+            const size_t pix = (size_t)(pbase[i] + (yy >> a.up) * Ws + (xx >> a.up));
+            p0[i] = ok ? a.src0 + pix * a.c0 : a.zeros;
+            p1[i] = (ok && a.src1) ? a.src1 + pix * a.c1 : a.zeros;
+        }
+    };
+
+    auto load_tile = [&](int cc) {
+        const int ch = cc + k4a * 4;                         // first of this thread's 4 channels in the tap
+        const int sel = ch < a.c0 ? 0 : (ch - a.c0 < a.c1 ? 1 : 2);
+        const int off = sel == 0 ? ch : sel == 1 ? ch - a.c0 : k4a * 4;
+        rsc = sel == 1 ? a.scale1 : a.scale0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* base = sel == 0 ? p0[i] : sel == 1 ? p1[i] : a.zeros;
+            ra[i] = *reinterpret_cast<const float4*>(base + off);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = wptr[(size_t)(kt * K4 + 2 * i) * a.cout];
+        for (int i = 0; i < 4; ++i) rb[i] = wp[i * wstep];
+        wp += wtile;
     };
 
     auto store_tile = [&](int buf) {
@@ -148,14 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
         for (int i = 0; i < 4; ++i) {
             float4 v = ra[i];
             if constexpr (PREC == VH_PREC_F32) {
-                const float sc = (okm >> i) & 1u ? rsc : 0.f;       // zero padding: silu(0) = 0
-                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                v.x *= rsc; v.y *= rsc; v.z *= rsc; v.w *= rsc;          // zero page * scale = 0; silu(0) = 0
                 if (a.pro == VH_PRO_SILU) {
                     v.x = mp_silu_dev(v.x); v.y = mp_silu_dev(v.y);
                     v.z = mp_silu_dev(v.z); v.w = mp_silu_dev(v.w);
                 }
-            } else {
-                if (!((okm >> i) & 1u)) v = zero4;                  // raw bf16 pairs: select, never multiply
             }
             sA[buf][k4a * BM + ((ma + 32 * i) ^ k4a)] = v;
         }
@@ -225,12 +230,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
 
     // ---- main loop ----------------------------------------------------------
     const int KT = a.k_pad / BK;
+    int tap = 0, cc = 0;
+    setup_tap(0);
     load_tile(0);
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
+        if (kt + 1 < KT) {
+            cc += BK;
+            if (cc >= a.cin_pad) {
+                cc = 0;
+                ++tap;
+                setup_tap(tap);
+            }
+            load_tile(cc);
+        }
         compute(buf);
         if (kt + 1 < KT) store_tile(buf ^ 1);
         __syncthreads();
@@ -289,8 +304,9 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.cout > 0, "vh_conv: bad geometry");
     VH_REQUIRE(a.c0 > 0 && a.c0 % 4 == 0, "vh_conv: c0 must be a positive multiple of 4 (got %d)", a.c0);
     VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 4 == 0) : a.c1 == 0, "vh_conv: bad c1 %d", a.c1);
-    VH_REQUIRE(a.cin_pad % 4 == 0 && a.cin_pad >= a.c0 + a.c1, "vh_conv: cin_pad %d < c0+c1 %d or not /4", a.cin_pad, a.c0 + a.c1);
-    VH_REQUIRE(a.k_pad % BK == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_conv: k_pad %d invalid for taps*cin_pad %d", a.k_pad, a.taps * a.cin_pad);
+    VH_REQUIRE(a.cin_pad % BK == 0 && a.cin_pad >= a.c0 + a.c1, "vh_conv: cin_pad %d must be a multiple of %d and >= c0+c1 = %d", a.cin_pad, BK, a.c0 + a.c1);
+    VH_REQUIRE(a.k_pad == a.taps * a.cin_pad, "vh_conv: k_pad %d != taps*cin_pad %d", a.k_pad, a.taps * a.cin_pad);
+    VH_REQUIRE(a.zeros && vh_aligned16(a.zeros) && a.zeros_bytes >= (size_t)a.cin_pad * 4 + 64, "vh_conv: zero page missing or smaller than cin_pad*4+64 bytes");
     VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.wt), "vh_conv: source/weight pointers must be 16-byte aligned");
     VH_REQUIRE(!a.up || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: up needs even output size");
     VH_REQUIRE(a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU, "vh_conv: bad prologue");
@@ -304,7 +320,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(MT * NT < (1LL << 31), "vh_conv: grid too large");
 
     ConvK k;
-    k.src0 = a.src0; k.src1 = a.src1; k.c0 = a.c0; k.c1 = a.c1; k.scale0 = a.scale0; k.scale1 = a.scale1;
+    k.src0 = a.src0; k.src1 = a.src1; k.zeros = a.zeros; k.c0 = a.c0; k.c1 = a.c1; k.scale0 = a.scale0; k.scale1 = a.scale1;
     k.h = a.h; k.w = a.w; k.up = a.up ? 1 : 0; k.pro = a.pro;
     k.wt = reinterpret_cast<const float4*>(a.wt); k.cin_pad = a.cin_pad; k.k_pad = a.k_pad; k.cout = a.cout;
     k.out = a.out; k.out_s8 = static_cast<unsigned short*>(a.out_s8); k.out_s8_c = a.out_s8_c; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;

@@ -370,7 +370,6 @@ extern "C" int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* p) {
     VH_REQUIRE(a.cout > 0 && a.cin > 0 && (a.taps == 1 || a.taps == 9), "vh_prep_weight: bad shape");
     VH_REQUIRE(a.cin_pad >= a.cin && a.cin_pad % 4 == 0, "vh_prep_weight: cin_pad %d", a.cin_pad);
     VH_REQUIRE(a.k_pad % 32 == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_prep_weight: k_pad %d", a.k_pad);
-    VH_REQUIRE(!a.split || a.cin_pad % 32 == 0, "vh_prep_weight: split weights need cin_pad %% 32 == 0 (got %d)", a.cin_pad);
     VH_REQUIRE(a.dst_col0 >= 0 && a.dst_col0 + a.cout <= a.dst_cols, "vh_prep_weight: destination columns out of range");
     return vh_dispatch(ctx, VH_TAG_PREP, 0.0, 4.0 * ((double)a.cout * a.cin * a.taps + (double)a.k_pad * a.cout), [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(prep_weight_k, dim3(a.cout), dim3(256), 0, s, a);

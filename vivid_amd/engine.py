@@ -151,6 +151,7 @@ class Engine:
         """K1 once per weight version: normalise, scale by gain/sqrt(fan_in), re-lay out
         (the reference repeats this on every forward, training/models.py:115-120)."""
         self._ensure_ctx(device)
+        self.zeros = torch.zeros(16384, dtype=torch.float32, device=device)     # 64 KiB zero page for vh_conv
         self.W.clear()
         self.embW.clear()
         self.programs.clear()
@@ -198,7 +199,7 @@ class Engine:
         w = self._params[key]
         cout, cin = w.shape[0], w.shape[1]
         split = 1 if (self.x3 and w.ndim == 4) else 0      # 2-D (linear) weights feed embed_k/linear_k: never split
-        cin_pad = _round_up(cin, 32 if split else 4)
+        cin_pad = _round_up(cin, 32 if w.ndim == 4 else 4)       # conv K-tiles are 32 channels of one tap
         k_pad = _round_up(taps * cin_pad, 32)
         wt = torch.empty(k_pad // 4 * cout * 4, dtype=torch.float32, device=w.device)
         a = L.PrepWeightArgs(w=w.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=k_pad,
@@ -222,7 +223,7 @@ class Engine:
             for k, shp in shapes.items():
                 if k.endswith("weight"):
                     taps = 9 if len(shp) == 4 and shp[-1] == 3 else 1
-                    cin_pad = _round_up(shp[1], 32 if (self.x3 and len(shp) == 4) else 4)
+                    cin_pad = _round_up(shp[1], 32 if len(shp) == 4 else 4)
                     self.W[k] = Weight(dummy, cin_pad, _round_up(taps * cin_pad, 32), shp[0], taps)
             self.embW = {}
             for prefix, spec in (("encoder.", self.enc_spec), ("unet.", self.unet_spec)):
@@ -277,7 +278,8 @@ class Engine:
         a = L.ConvArgs(src0=s0.ptr, src1=s1.ptr if s1 is not None else None,
                        c0=s0.shape[-1], c1=s1.shape[-1] if s1 is not None else 0,
                        scale0=sc0, scale1=sc1, rows=rows, h=h, w=w, up=up, taps=W.taps, pro=pro,
-                       wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad, cout=W.cout,
+                       wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad,
+                       zeros=self.zeros.data_ptr() if getattr(self, "zeros", None) is not None else None, zeros_bytes=65536, cout=W.cout,
                        out=out.ptr if out is not None else None, out_s8=out_s8.ptr if out_s8 is not None else None,
                        out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
