@@ -34,22 +34,16 @@ struct AttnXK {
 };
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float v) {
-    const unsigned u = __float_as_uint(v);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
 }
 
-// 8 floats -> bf16x8 hi and lo fragments
+// 8 floats -> bf16x8 hi and lo fragments (plain casts: hipcc emits v_cvt_pk_bf16_f32, round to nearest even)
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
-    unsigned h[8], l[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        h[j] = bf16_rn_bits(v[j]);
-        l[j] = bf16_rn_bits(v[j] - __uint_as_float(h[j] << 16));
+        hi[j] = (__bf16)v[j];
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
     }
-    uint4 hp = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    uint4 lp = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-    hi = *reinterpret_cast<bf16x8*>(&hp);
-    lo = *reinterpret_cast<bf16x8*>(&lp);
 }
 
 template <int D, int NW>

@@ -27,9 +27,8 @@ __device__ __forceinline__ float mp_silu_dev(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
 }
 
-__device__ __forceinline__ unsigned bf16_rn_bits(float v) {
-    const unsigned u = __float_as_uint(v);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+__device__ __forceinline__ unsigned bf16_rn_bits(float v) {      // v_cvt_pk_bf16_f32: round to nearest even
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
 }
 __device__ __forceinline__ void split_bf16(float v, unsigned& hi, unsigned& lo) {
     hi = bf16_rn_bits(v);
