@@ -17,6 +17,7 @@
 // The running max is only raised (and O rescaled) when some query's max grew by more than 2^8
 // (fp32 accumulators: no precision is lost by the deferred scale).
 #include "ctx.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -85,73 +86,77 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float mrow = a.n_zero > 0.f ? 0.f : -1e30f;
+    // Running max starts at 0 — exact for the zero-logit phantom keys; without them the first 32-key
+    // sub-tile replaces it by its own max before anything is exponentiated (see `first` below).
+    float mrow = 0.f;
     float lsum = a.n_zero;
 
-    // ---- staging maps ---------------------------------------------------------------------------
+    // ---- staging maps (all per-thread addresses are loop-invariant; a tile only advances the pointers) ----
     constexpr int KPT = K_UNITS / NT, VPT = V_UNITS / NT;   // units per thread per tile
     const uint4* Kb = a.k + (size_t)bh * a.klp * KU;
     const uint4* Vb = a.vt + (size_t)bh * D * 2 * (a.klp / 8);
+    const uint4* kp[KPT];
+    const uint4* vp[VPT];
+    int ksl[KPT], vsl[VPT], kkey[KPT], vku[VPT];             // LDS slots; key / key-unit of each staged unit
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const int idx = t + i * NT;
+        const int key = idx / KU, u = idx - key * KU;
+        kp[i] = Kb + (size_t)key * KU + u;
+        ksl[i] = u * KT + (key ^ (u & 7));
+        kkey[i] = key;
+    }
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = t + i * NT;
+        const int row = idx >> 3, ku = idx & 7;               // row = d*2 + hl
+        const int d = row >> 1, hl = row & 1;
+        vp[i] = Vb + (size_t)row * (a.klp / 8) + ku;
+        vsl[i] = d * 16 + ((hl * 8 + ku) ^ (d & 15));
+        vku[i] = ku;
+    }
     uint4 rk[KPT], rv[VPT];
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&]() {                                   // klp is a multiple of KT: always in range
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const int idx = t + i * NT;
-            const int key = idx / KU, u = idx - key * KU;
-            rk[i] = Kb[(size_t)(k0 + key) * KU + u];            // klp is a multiple of KT: always in range
-        }
+        for (int i = 0; i < KPT; ++i) { rk[i] = *kp[i]; kp[i] += KT * KU; }
 #pragma unroll
-        for (int i = 0; i < VPT; ++i) {
-            const int idx = t + i * NT;
-            const int row = idx >> 3, ku = idx & 7;               // row = d*2 + hl
-            rv[i] = Vb[(size_t)row * (a.klp / 8) + (k0 >> 3) + ku];
-        }
+        for (int i = 0; i < VPT; ++i) { rv[i] = *vp[i]; vp[i] += KT / 8; }
     };
-    auto store_tile = [&](int buf, int k0) {
+    auto store_tile = [&](int buf, int k0, bool tail) {
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
-            const int idx = t + i * NT;
-            const int key = idx / KU, u = idx - key * KU;
-            sK[buf][u * KT + (key ^ (u & 7))] = (k0 + key < a.kl) ? rk[i] : zero4;
+            uint4 v = rk[i];
+            if (tail && k0 + kkey[i] >= a.kl) v = zero4;
+            sK[buf][ksl[i]] = v;
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
-            const int idx = t + i * NT;
-            const int row = idx >> 3, ku = idx & 7;
-            const int d = row >> 1, hl = row & 1;
             uint4 v = rv[i];
-            if (k0 + (ku >> 1) * 16 + 16 > a.kl) {                // the unit's 16-key group reaches past the end: zero invalid keys
+            if (tail && k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {   // the unit's 16-key group reaches past the end
                 unsigned short* e = reinterpret_cast<unsigned short*>(&v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    // position j of the unit holds key (pos with bits 2,3 swapped); groups of 8 map to themselves
-                    const int pos = ku * 8 + j;
+                    const int pos = vku[i] * 8 + j;               // position -> key: bits 2 and 3 swapped
                     const int key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
                     if (k0 + key >= a.kl) e[j] = 0;
                 }
             }
-            sV[buf][d * 16 + ((hl * 8 + ku) ^ (d & 15))] = v;
+            sV[buf][vsl[i]] = v;
         }
     };
 
-    const int ntiles = (a.kl + KT - 1) / KT;
-    load_tile(0);
-    store_tile(0, 0);
-    __syncthreads();
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int buf = tile & 1;
-        const int k0 = tile * KT;
-        if (tile + 1 < ntiles) load_tile(k0 + KT);
-        const bool tail = k0 + KT > a.kl;
-
+    // One 64-key tile.  TAIL (last tile, kl % 64 != 0) masks keys >= kl; full tiles carry no mask code.
+    auto tile_body = [&](int buf, int k0, auto tailc) {
+        constexpr bool TAIL = decltype(tailc)::value;
+        const bool first_tile = (k0 == 0) && !(a.n_zero > 0.f);
 #pragma unroll
         for (int ks = 0; ks < KT / 32; ++ks) {
-            // ---- S^T = K Q^T ---------------------------------------------------------------------
+            // ---- S^T - m = K Q^T - m : the running max enters as the initial accumulator -------------
             f32x16 sacc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[r] = -mrow;
             const int key = ks * 32 + lr;
 #pragma unroll
             for (int sl = 0; sl < D / 16; ++sl) {
@@ -162,22 +167,28 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[sl], sacc, 0, 0, 0);
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[sl], sacc, 0, 0, 0);
             }
-            // ---- online softmax ------------------------------------------------------------------
-            if (tail) {
+            if constexpr (TAIL) {
                 const int kbase = k0 + ks * 32 + 4 * hh;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kbase + (r & 3) + 8 * (r >> 2) >= a.kl) sacc[r] = -INFINITY;
             }
+            // ---- online softmax; sacc holds s - mrow ---------------------------------------------------
             float mx = sacc[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (__any(mx > mrow + RESCALE_THR)) {          // wave-uniform: raise the running max for every query
-                const float mnew = fmaxf(mrow, mx);
-                const float alpha = __builtin_amdgcn_exp2f(mrow - mnew);
+            if (first_tile && ks == 0) {                    // no max yet: adopt this sub-tile's (O and l are still 0)
+                mrow = mx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] -= mx;
+            } else if (__any(mx > RESCALE_THR)) {           // wave-uniform: raise the running max for every query
+                const float dm = fmaxf(mx, 0.f);            // new max - old max
+                const float alpha = __builtin_amdgcn_exp2f(-dm);
                 lsum *= alpha;
-                mrow = mnew;
+                mrow += dm;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] -= dm;
 #pragma unroll
                 for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
             float rs = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                pv[r] = __builtin_amdgcn_exp2f(sacc[r] - mrow);
+                pv[r] = __builtin_amdgcn_exp2f(sacc[r]);
                 rs += pv[r];
             }
             rs += __shfl_xor(rs, 32);
@@ -209,7 +220,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
                 }
             }
         }
-        if (tile + 1 < ntiles) store_tile(buf ^ 1, k0 + KT);
+    };
+
+    const int ntiles = (a.kl + KT - 1) / KT;
+    const bool ragged = (a.kl % KT) != 0;
+    load_tile();
+    store_tile(0, 0, ragged && ntiles == 1);
+    __syncthreads();
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int buf = tile & 1;
+        const int k0 = tile * KT;
+        const bool last = tile + 1 == ntiles;
+        if (!last) load_tile();
+        if (last && ragged) tile_body(buf, k0, std::true_type{});
+        else tile_body(buf, k0, std::false_type{});
+        if (!last) store_tile(buf ^ 1, k0 + KT, ragged && tile + 2 == ntiles);
         __syncthreads();
     }
 
