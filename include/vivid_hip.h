@@ -80,7 +80,8 @@ typedef struct {
     float gain_value;
     float* wt;           /* [k_pad/4][dst_cols][4] */
     int dst_col0, dst_cols;
-    int split;           /* 1: bf16 hi/lo split, wt[(k/8)*2 + hl][dst_cols][8 bf16], hl = 0 hi / 1 lo (same byte count) */
+    int split;           /* 1: bf16 hi/lo split, wt[(k/8)*2 + hl][dst_cols][8 bf16], hl = 0 hi / 1 lo (same byte count);
+                            2: the same split, output-channel major: wt[col][(k/8)*2 + hl][8 bf16] (VH_CONV_GLDS256) */
 } vh_prep_weight_args;
 int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* a);
 
@@ -103,6 +104,7 @@ enum { VH_PREC_F32 = 0, VH_PREC_BF16X3 = 1 };
  * of 8 channels, 8 bf16 hi followed by 8 bf16 lo (4 bytes per channel, channel count a multiple of 32, pad
  * channels zero), produced by vh_split / vh_pixnorm / a vh_conv S8 epilogue; weights from vh_prep_weight
  * with split=1.  Scaling, mp_silu and the mp_cat concat are applied by the producer of the S8 tensor. */
+enum { VH_CONV_TILE128 = 0, VH_CONV_GLDS256 = 1 };   /* 128x128 register-staged tile | 256-wide direct-to-LDS tile */
 enum { VH_PRO_NONE = 0, VH_PRO_SILU = 1 };
 enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2 };
 typedef struct {
@@ -120,6 +122,7 @@ typedef struct {
     float* out;                            /* [rows*h*w][cout] fp32; may be NULL if out_s8 is given */
     void* out_s8; int out_s8_c;            /* optional S8 copy of the result (cout % 32 == 0, out_s8_c == cout) */
     int prec;                              /* VH_PREC_* */
+    int kernel;                            /* VH_CONV_TILE128 (weights split 0/1) or VH_CONV_GLDS256 (bf16x3 only, weights split 2) */
     int epi;
     const float* cvec; int cvec_ld;        /* SCALE_SILU: cvec[row*cvec_ld + o] */
     const float* res; int res_up;          /* MPSUM */

@@ -69,13 +69,16 @@ def test_conv_store_fp32(ctx, rows, h, w, cin, cout, taps):
     out = torch.empty(rows, h, w, cout, device="cuda")
     ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
                                   taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=out.data_ptr(),
-                                  out_s8=None, out_s8_c=0, prec=0, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0))
+                                  out_s8=None, out_s8_c=0, prec=0, kernel=0, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), _nhwc(ref)) < 2e-5
 
 
-@pytest.mark.parametrize("prec", [0, 1])
-def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
+MODES = [(0, 0), (1, 0), (1, 1)]     # (prec, kernel): fp32 tile128 | bf16x3 tile128 | bf16x3 glds256
+
+
+@pytest.mark.parametrize("prec,KERN", MODES)
+def test_conv_res0_path_concat_up_silu_scale(ctx, prec, KERN):
     """Decoder conv_res0: mp_silu(mp_cat(up(x), skip)) -> conv3x3 -> mp_silu(y*c)   (models.py:167,174-176,403)."""
     from vivid_amd import _lib as L
     g = torch.Generator().manual_seed(7)
@@ -90,12 +93,12 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
     Cc = math.sqrt((ca + cb) / ((1 - t) ** 2 + t ** 2))
     wa, wb = Cc / math.sqrt(ca) * (1 - t), Cc / math.sqrt(cb) * t
     xd, sd, cd = _nhwc(x).cuda(), _nhwc(skip).cuda(), c.cuda()
-    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=prec)
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=(2 if KERN else 1) if prec else 0)
     out = torch.empty(rows, h, w, cout, device="cuda")
     if prec == 0:
         ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=sd.data_ptr(), c0=ca, c1=cb, scale0=wa, scale1=wb, rows=rows, h=h, w=w,
                                       up=0, taps=9, pro=1, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=out.data_ptr(),
-                                      out_s8=None, out_s8_c=0, prec=0, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0, ta=0, tb=0, clip=0))
+                                      out_s8=None, out_s8_c=0, prec=0, kernel=0, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0, ta=0, tb=0, clip=0))
         got = out
     else:
         s8 = torch.empty(rows * h * w * cin_pad, device="cuda")
@@ -104,7 +107,7 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
         o8 = torch.empty(rows * h * w * cout, device="cuda")
         ctx.call("vh_conv", L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin_pad, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
                                       up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=None,
-                                      out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0,
+                                      out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, kernel=KERN, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0,
                                       ta=0, tb=0, clip=0))
         torch.cuda.synchronize()
         got = _s8_decode(o8, (rows, h, w, cout))
@@ -112,8 +115,8 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec):
     assert rel_l2(got.cpu(), _nhwc(ref)) < (2e-5 if prec == 0 else 1e-4)
 
 
-@pytest.mark.parametrize("prec", [0, 1])
-def test_conv_up_mpsum_clip(ctx, prec):
+@pytest.mark.parametrize("prec,KERN", MODES)
+def test_conv_up_mpsum_clip(ctx, prec, KERN):
     """'up' block: conv_res1 epilogue mp_sum(resample_up(x), y, 0.3) with clip   (models.py:60-61,184,204-205)."""
     from vivid_amd import _lib as L
     g = torch.Generator().manual_seed(11)
@@ -123,7 +126,7 @@ def test_conv_up_mpsum_clip(ctx, prec):
     wgt = torch.randn(c, c, 3, 3, generator=g)
     ref = R.mp_sum(R.resample(xlow, "up"), R.mp_conv(y_in, wgt), t=0.3).clip(-2.0, 2.0)
     n = math.sqrt(0.7 ** 2 + 0.3 ** 2)
-    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=prec)
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=(2 if KERN else 1) if prec else 0)
     yd, rd = _nhwc(y_in).cuda(), _nhwc(xlow).cuda()
     src = yd
     if prec == 1:
@@ -133,7 +136,7 @@ def test_conv_up_mpsum_clip(ctx, prec):
     out = torch.empty(rows, h, w, c, device="cuda")
     ctx.call("vh_conv", L.ConvArgs(src0=src.data_ptr(), src1=None, c0=cin_pad if prec else c, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
                                   up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=c, out=out.data_ptr(),
-                                  out_s8=None, out_s8_c=0, prec=prec, epi=2, cvec=None, cvec_ld=0, res=rd.data_ptr(), res_up=1,
+                                  out_s8=None, out_s8_c=0, prec=prec, kernel=KERN if prec else 0, epi=2, cvec=None, cvec_ld=0, res=rd.data_ptr(), res_up=1,
                                   ta=0.7 / n, tb=0.3 / n, clip=2.0))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), _nhwc(ref)) < (2e-5 if prec == 0 else 1e-4)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Time vh_conv variants on one shape: python tools/conv_bench.py rows h w cin cout [taps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vivid_amd import _lib as L
+
+rows, h, w, cin, cout = [int(x) for x in sys.argv[1:6]]
+taps = int(sys.argv[6]) if len(sys.argv) > 6 else 9
+ctx = L.Context(torch.cuda.current_stream().cuda_stream)
+g = torch.Generator().manual_seed(0)
+x = torch.randn(rows, h, w, cin, generator=g).cuda()
+wgt = torch.randn(cout, cin, *([3, 3] if taps == 9 else [1, 1]), generator=g).cuda()
+zeros = torch.zeros(16384, device="cuda")
+cin_pad = (cin + 31) // 32 * 32
+k_pad = taps * cin_pad
+M = rows * h * w
+flops = 2.0 * M * cout * cin * taps
+s8 = torch.empty(M * cin_pad, device="cuda")
+ctx.call("vh_split", L.SplitArgs(src0=x.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin_pad, out=s8.data_ptr(), out_raw=None))
+outs = {}
+for name, prec, kern, split in (("fp32-tile128", 0, 0, 0), ("x3-tile128", 1, 0, 1), ("x3-glds256", 1, 1, 2)):
+    wt = torch.zeros(k_pad // 4 * cout * 4, device="cuda")
+    ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=k_pad, gain_ptr=None,
+                                                gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=split))
+    out = torch.empty(M, cout, device="cuda")
+    a = L.ConvArgs(src0=(s8 if prec else x).data_ptr(), src1=None, c0=cin_pad if prec else cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
+                   up=0, taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, cout=cout,
+                   out=out.data_ptr(), out_s8=None, out_s8_c=0, prec=prec, kernel=kern, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0)
+    for _ in range(2):
+        ctx.call("vh_conv", a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 5
+    e0.record()
+    for _ in range(n):
+        ctx.call("vh_conv", a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    outs[name] = out
+    err = float((out - outs["fp32-tile128"]).norm() / outs["fp32-tile128"].norm())
+    print(f"{name:14s} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TF/s  rel-vs-fp32 {err:.1e}")

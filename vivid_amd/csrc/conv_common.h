@@ -1,0 +1,83 @@
+// Shared pieces of the convolution kernels (conv_igemm.hip: 128x128 register-staged tile, fp32 and bf16x3;
+// conv_x3.hip: 256-wide direct-to-LDS tile, bf16x3).
+#pragma once
+#include "ctx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace vhconv {
+
+struct ConvK {
+    const float* src0; const float* src1; const float* zeros;
+    int c0, c1; float scale0, scale1;
+    int h, w, up, pro;
+    const float4* wt; int cin_pad, k_pad, cout;
+    float* out; unsigned short* out_s8; int out_s8_c; int epi;
+    const float* cvec; int cvec_ld;
+    const float* res; int res_up;
+    float ta, tb, clip;
+    int M, HW, NT;
+};
+
+__device__ __forceinline__ float mp_silu_dev(float v) {
+    // silu(v)/0.596 = v / (1 + exp(-v)) / 0.596
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * v);
+    return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
+}
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float v) {      // v_cvt_pk_bf16_f32: round to nearest even
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
+}
+
+// x ~= hi + lo, both bf16 (round to nearest even); written into the S8 layout.
+__device__ __forceinline__ void store_s8(unsigned short* base, size_t pix, int cpad, int ch, float v) {
+    const unsigned hi = bf16_rn_bits(v);
+    const unsigned lo = bf16_rn_bits(v - __uint_as_float(hi << 16));
+    unsigned short* p = base + (pix * cpad + (size_t)(ch & ~7)) * 2 + (ch & 7);
+    p[0] = (unsigned short)hi;
+    p[8] = (unsigned short)lo;
+}
+
+
+// Epilogue of ONE 32x32 accumulator tile (passed by value so the kernel's accumulator array never has its
+// address taken - a by-reference array of f32x16 ends up in scratch).  C/D map of the 32x32 MFMA:
+// column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  row0: first pixel row of the tile; gn: this lane's column.
+__device__ __forceinline__ void conv_epilogue_tile(const ConvK& a, const f32x16 accv, int row0, int gn, int hh) {
+    if (gn >= a.cout) return;
+    const int Hr = a.h >> 1, Wr = a.w >> 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int gm = row0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (gm >= a.M) continue;
+        float y = accv[r];
+        if (a.epi == VH_EPI_SCALE_SILU) {
+            const int img = gm / a.HW;
+            y = mp_silu_dev(y * a.cvec[(size_t)img * a.cvec_ld + gn]);
+        } else if (a.epi == VH_EPI_MPSUM) {
+            size_t rrow = (size_t)gm;
+            if (a.res_up) {
+                const int img = gm / a.HW;
+                const int rem = gm - img * a.HW;
+                const int yy = rem / a.w, xx = rem - yy * a.w;
+                rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
+            }
+            y = a.res[rrow * a.cout + gn] * a.ta + y * a.tb;
+            if (a.clip > 0.f) y = fminf(fmaxf(y, -a.clip), a.clip);
+        }
+        if (a.out) a.out[(size_t)gm * a.cout + gn] = y;
+        if (a.out_s8) store_s8(a.out_s8, (size_t)gm, a.out_s8_c, gn, y);
+    }
+}
+
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+// workgroup ids b, b+8, b+16, ... share an L2.  Give each of those 8 groups one contiguous run of tiles
+// (bijective for any grid size): adjacent pixel tiles - which re-read each other's halo rows - and the
+// N-tiles of one pixel tile then hit the same L2.
+__device__ __forceinline__ unsigned xcd_tile_id() {
+    const unsigned G = gridDim.x, bid = blockIdx.x;
+    const unsigned q = G >> 3, r = G & 7u, xcd = bid & 7u, i = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+}
+
+}  // namespace vhconv

@@ -29,45 +29,12 @@
 //                    weights are pre-split by vh_prep_weight.  LDS unit u = 2*(8-channel chunk) + {hi,lo}.
 // Pipeline: global -> registers for tile t+1 is issued before the MFMAs of tile t, written
 //   to the other LDS buffer after them; one barrier per K-tile.
-#include "ctx.h"
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#include "conv_common.h"
 
 namespace {
+using namespace vhconv;
 
 constexpr int BM = 128, BN = 128, BK = 32, K4 = BK / 4;
-
-struct ConvK {
-    const float* src0; const float* src1; const float* zeros;
-    int c0, c1; float scale0, scale1;
-    int h, w, up, pro;
-    const float4* wt; int cin_pad, k_pad, cout;
-    float* out; unsigned short* out_s8; int out_s8_c; int epi;
-    const float* cvec; int cvec_ld;
-    const float* res; int res_up;
-    float ta, tb, clip;
-    int M, HW, NT;
-};
-
-__device__ __forceinline__ float mp_silu_dev(float v) {
-    // silu(v)/0.596 = v / (1 + exp(-v)) / 0.596
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896341f * v);
-    return v * __builtin_amdgcn_rcpf(1.0f + e) * (1.0f / 0.596f);
-}
-
-__device__ __forceinline__ unsigned bf16_rn_bits(float v) {      // v_cvt_pk_bf16_f32: round to nearest even
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
-}
-
-// x ~= hi + lo, both bf16 (round to nearest even); written into the S8 layout.
-__device__ __forceinline__ void store_s8(unsigned short* base, size_t pix, int cpad, int ch, float v) {
-    const unsigned hi = bf16_rn_bits(v);
-    const unsigned lo = bf16_rn_bits(v - __uint_as_float(hi << 16));
-    unsigned short* p = base + (pix * cpad + (size_t)(ch & ~7)) * 2 + (ch & 7);
-    p[0] = (unsigned short)hi;
-    p[8] = (unsigned short)lo;
-}
 
 template <int TAPS, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
@@ -75,7 +42,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
     __shared__ float4 sB[2][K4 * BN];
 
     const int t = threadIdx.x;
-    const int nt = blockIdx.x % a.NT, mt = blockIdx.x / a.NT;
+    const unsigned tile = xcd_tile_id();
+    const int nt = tile % a.NT, mt = tile / a.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- staging maps -----------------------------------------------------
@@ -251,43 +219,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
     }
 
     // ---- epilogue -----------------------------------------------------------
-    // C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const int Hr = a.h >> 1, Wr = a.w >> 1;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (gm >= a.M) continue;
-            int img = 0;
-            size_t rrow = (size_t)gm;
-            if (a.epi == VH_EPI_SCALE_SILU || (a.epi == VH_EPI_MPSUM && a.res_up)) {
-                img = gm / a.HW;
-                if (a.epi == VH_EPI_MPSUM) {
-                    const int rem = gm - img * a.HW;
-                    const int y = rem / a.w, x = rem - y * a.w;
-                    rrow = (size_t)((img * Hr + (y >> 1)) * Wr + (x >> 1));
-                }
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int gn = n0 + wn * 64 + ni * 32 + lr;
-                if (gn >= a.cout) continue;
-                float y = acc[mi][ni][r];
-                if (a.epi == VH_EPI_SCALE_SILU) {
-                    y = mp_silu_dev(y * a.cvec[(size_t)img * a.cvec_ld + gn]);
-                } else if (a.epi == VH_EPI_MPSUM) {
-                    y = a.res[rrow * a.cout + gn] * a.ta + y * a.tb;
-                    if (a.clip > 0.f) y = fminf(fmaxf(y, -a.clip), a.clip);
-                }
-                if (a.out) a.out[(size_t)gm * a.cout + gn] = y;
-                if (a.out_s8) store_s8(a.out_s8, (size_t)gm, a.out_s8_c, gn, y);
-            }
-        }
-    }
+        for (int ni = 0; ni < 2; ++ni)
+            conv_epilogue_tile(a, acc[mi][ni], m0 + wm * 64 + mi * 32, n0 + wn * 64 + ni * 32 + lr, hh);
 }
 
 }  // namespace
+
+int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, vhconv::ConvK k, double flops, double bytes);
 
 extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_conv: null args");
@@ -333,6 +274,9 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     const double in_px = a.up ? (double)M / 4 : (double)M;
     double bytes = 4.0 * (in_px * cin + cin * a.taps * a.cout + (double)M * a.cout);
     if (a.epi == VH_EPI_MPSUM) bytes += 4.0 * (a.res_up ? (double)M / 4 : (double)M) * a.cout;
+    VH_REQUIRE(a.kernel == VH_CONV_TILE128 || (a.kernel == VH_CONV_GLDS256 && a.prec == VH_PREC_BF16X3),
+               "vh_conv: kernel %d unknown or not available for this precision", a.kernel);
+    if (a.kernel == VH_CONV_GLDS256) return vh_conv_x3_glds_dispatch(ctx, a, k, flops, bytes);
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, prec, grid](hipStream_t s) -> int {
         if (prec == VH_PREC_BF16X3) {
             if (taps == 9) hipLaunchKernelGGL((conv_igemm<9, VH_PREC_BF16X3>), dim3(grid), dim3(256), 0, s, k);

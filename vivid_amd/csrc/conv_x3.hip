@@ -1,0 +1,208 @@
+// bf16x3 implicit-GEMM convolution, 256-pixel tiles, direct-to-LDS staging (gfx950).
+//
+// Same operation and epilogues as conv_igemm.hip (reference training/models.py:123-126 with the fused
+// element-wise ops listed there); this is the throughput kernel of the bf16x3 mode.  What changed and why
+// (numbers from profiles/: the 128x128 register-staged kernel sits at ~34 % of the bf16 MFMA peak with its
+// LDS store path (ds_write_b128, ~79 B/clk/CU) and address VALU as busy as the matrix pipe):
+//   * one workgroup = 8 waves computes 256 pixels x 256 (or 128) output channels, each wave 128x64 (or 64x64):
+//     half the LDS bytes and staging instructions per MFMA;
+//   * operand tiles go global -> LDS with global_load_lds_dwordx4 (no VGPR round trip, no ds_write); the
+//     LDS image is [row][8 units] with unit' = unit ^ ((row>>1)&7), applied on the SOURCE side (the DMA writes
+//     64 consecutive 16-byte slots per wave instruction; a lane picks which unit of which row it fetches), so
+//     8 lanes still read one 128-byte line of one pixel and ds_read_b128 of 32 consecutive rows is conflict-free;
+//   * weights are laid out [cout][K] in the same S8 chunking as activations, so B tiles stage exactly like A.
+// K runs tap-major in 32-channel tiles; per tap each thread derives its 4 pixel pointers (zero page outside
+// the image).  Two LDS stages; the loads of tile t+1 are in flight during the MFMAs of tile t.
+#include "conv_common.h"
+
+namespace {
+using namespace vhconv;
+
+constexpr int BK = 32;
+
+// 16-byte direct global -> LDS load (LDS-DMA): every lane supplies its own global source, the LDS destination is
+// the wave-uniform `lds_wave_base` + lane*16.  Written as inline asm so that hipcc does not count it: with the
+// builtin the compiler drains the DMA (s_waitcnt vmcnt(0)) before the first ds_read that follows, which would
+// serialise load and compute; here the kernel waits for it by hand, once per K-tile, just before the barrier
+// that publishes the stage (cdna_hip_programming.md 5.7: M0 carries the LDS address and is saved/restored inside
+// the statement).  Compiled in the device pass only (a templated __global__ function that contains the builtin
+// or this asm directly gets no host launch stub from hipcc).
+__device__ __forceinline__ void glds16(const float4* gsrc, float4* lds_wave_base) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+#endif
+}
+
+__device__ __forceinline__ void wait_dma() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
+template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI>
+__global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
+    static_assert(WAVES_M * WAVES_N == 8, "8 waves");
+    constexpr int BM = WAVES_M * MI * 32, BN = WAVES_N * NI * 32;
+    constexpr int RA = BM / 64, RB = BN / 64;             // glds rounds: 512 slots (64 rows x 8 units) per round
+    __shared__ float4 sA[2][BM * 8];
+    __shared__ float4 sB[2][BN * 8];
+
+    const int t = threadIdx.x;
+    const int w = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
+    const unsigned tile = xcd_tile_id();
+    const int nt = tile % a.NT, mt = tile / a.NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- staging maps ---------------------------------------------------------------------------------
+    // slot (round j, wave w, lane l) = j*512 + w*64 + l  ->  row = slot>>3 = j*64 + w*8 + (l>>3), unit' = l&7.
+    // (row>>1)&7 = ((w&1)<<2) | (l>>4) for every round, so a thread fetches the same unit u of RA (RB) rows.
+    const int rsub = w * 8 + (l >> 3);
+    const int u = (l & 7) ^ (((w & 1) << 2) | (l >> 4));
+    const int Hs = a.up ? (a.h >> 1) : a.h, Ws = a.up ? (a.w >> 1) : a.w;
+    int py[RA], px[RA], pbase[RA];
+    bool pv[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int gm = m0 + j * 64 + rsub;
+        pv[j] = gm < a.M;
+        const int g = pv[j] ? gm : 0;
+        const int img = g / a.HW;
+        const int rem = g - img * a.HW;
+        py[j] = rem / a.w;
+        px[j] = rem - py[j] * a.w;
+        pbase[j] = img * Hs * Ws;
+    }
+    const float4* pa[RA];                                  // per-tap A pointers (already + unit u)
+    const float4* pb[RB];                                  // B pointers, advanced by 8 units per K-tile
+    const float4* zp = reinterpret_cast<const float4*>(a.zeros);
+    const int KU = a.k_pad >> 2;                           // 16-byte units per weight row
+    bool bzero[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int gn = n0 + j * 64 + rsub;
+        bzero[j] = gn >= a.cout;
+        pb[j] = bzero[j] ? zp : a.wt + (size_t)gn * KU + u;
+    }
+
+    auto setup_tap = [&](int tap) {
+        int dy = 0, dx = 0;
+        if (TAPS == 9) {
+            const int ty = tap / 3;
+            dy = ty - 1;
+            dx = tap - ty * 3 - 1;
+        }
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int yy = py[j] + dy, xx = px[j] + dx;
+            const bool ok = pv[j] && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+            const size_t pix = (size_t)(pbase[j] + (yy >> a.up) * Ws + (xx >> a.up));
+            pa[j] = ok ? reinterpret_cast<const float4*>(a.src0 + pix * a.c0) + u : zp;
+        }
+    };
+
+    // issue the DMA of one K-tile (cc = channel offset inside the tap) into LDS stage `st`
+    auto issue = [&](int st, int cc) {
+        const int cu = cc >> 2;                            // channel offset in 16-byte units
+#pragma unroll
+        for (int j = 0; j < RA; ++j)
+            glds16(pa[j] + cu, &sA[st][j * 512 + w * 64]);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            glds16(pb[j], &sB[st][j * 512 + w * 64]);
+            if (!bzero[j]) pb[j] += 8;
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm = w / WAVES_N, wn = w % WAVES_N;
+    const int swz = (lr >> 1) & 7;                         // (row>>1)&7 of every row this lane reads
+    const int arow = (wm * MI * 32 + lr) * 8, brow = (wn * NI * 32 + lr) * 8;
+
+    auto compute = [&](int st) {
+#pragma unroll
+        for (int sl = 0; sl < BK / 16; ++sl) {
+            // 32x32x16 bf16: lane (row = l&31, h = l>>5) supplies k = 8h..8h+7 of the slab = chunk 2*sl + h
+            const int uh = ((sl * 2 + hh) * 2) ^ swz, ul = ((sl * 2 + hh) * 2 + 1) ^ swz;
+            bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[st][arow + mi * 256 + uh]);
+                al[mi] = *reinterpret_cast<const bf16x8*>(&sA[st][arow + mi * 256 + ul]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                bh[ni] = *reinterpret_cast<const bf16x8*>(&sB[st][brow + ni * 256 + uh]);
+                bl[ni] = *reinterpret_cast<const bf16x8*>(&sB[st][brow + ni * 256 + ul]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+
+    // ---- main loop: DMA of tile t+1 in flight during the MFMAs of tile t; one barrier per tile ------------
+    const int KT = a.k_pad / BK;
+    int tap = 0, cc = 0;
+    setup_tap(0);
+    issue(0, 0);
+    wait_dma();
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < KT) {
+            cc += BK;
+            if (cc >= a.cin_pad) {
+                cc = 0;
+                ++tap;
+                setup_tap(tap);
+            }
+            issue(st ^ 1, cc);
+        }
+        compute(st);
+        wait_dma();                                        // this wave's DMA of tile kt+1 has landed ...
+        __syncthreads();                                   // ... and so has every other wave's
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            conv_epilogue_tile(a, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32 + lr, hh);
+}
+
+}  // namespace
+
+// Entry used by vh_conv for prec == VH_PREC_BF16X3 && kernel == VH_CONV_GLDS (arguments already validated).
+int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
+    const long long M = k.M;
+    const bool wide = a.cout % 256 == 0;                   // 256x256 tile; otherwise 256x128
+    const int BN = wide ? 256 : 128;
+    const long long MT = (M + 255) / 256, NT = (a.cout + BN - 1) / BN;
+    if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
+    k.NT = (int)NT;
+    const unsigned grid = (unsigned)(MT * NT);
+    const int taps = a.taps;
+    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, wide, grid](hipStream_t s) -> int {
+        if (taps == 9 && wide) hipLaunchKernelGGL((conv_x3_glds<9, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
+        else if (taps == 9) hipLaunchKernelGGL((conv_x3_glds<9, 4, 2, 2, 2>), dim3(grid), dim3(512), 0, s, k);
+        else if (wide) hipLaunchKernelGGL((conv_x3_glds<1, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
+        else hipLaunchKernelGGL((conv_x3_glds<1, 4, 2, 2, 2>), dim3(grid), dim3(512), 0, s, k);
+        return vh_check_launch("conv_x3_glds");
+    });
+}

@@ -51,7 +51,13 @@ __global__ __launch_bounds__(256) void prep_weight_k(vh_prep_weight_args a) {
         const int tap = k / a.cin_pad, ci = k - tap * a.cin_pad;
         float v = 0.f;
         if (tap < a.taps && ci < a.cin) v = w[ci * a.taps + tap] * scale;
-        if (a.split) {
+        if (a.split == 2) {
+            unsigned hi, lo;
+            split_bf16(v, hi, lo);
+            unsigned short* ws = reinterpret_cast<unsigned short*>(a.wt) + (size_t)(a.dst_col0 + o) * a.k_pad * 2;
+            ws[(size_t)(k >> 3) * 16 + (k & 7)] = (unsigned short)hi;
+            ws[(size_t)(k >> 3) * 16 + 8 + (k & 7)] = (unsigned short)lo;
+        } else if (a.split) {
             unsigned hi, lo;
             split_bf16(v, hi, lo);
             unsigned short* ws = reinterpret_cast<unsigned short*>(a.wt);

@@ -116,7 +116,9 @@ class Engine:
         if precision not in ("fp32", "bf16x3"):
             raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {precision!r}")
         self.precision = precision
-        self.x3 = precision == "bf16x3"      # 3x3 convs on the bf16 hi/lo split MFMA path
+        self.x3 = precision == "bf16x3"      # convs/attention on the bf16 hi/lo split MFMA path
+        import os
+        self.glds = self.x3 and os.environ.get("VIVID_CONV_KERNEL", "glds256") != "tile128"
         self.cfg = cfg
         self.dual = dual_source
         self.nsrc = 2 if dual_source else 1
@@ -198,7 +200,8 @@ class Engine:
     def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None):
         w = self._params[key]
         cout, cin = w.shape[0], w.shape[1]
-        split = 1 if (self.x3 and w.ndim == 4) else 0      # 2-D (linear) weights feed embed_k/linear_k: never split
+        # 2-D (linear) weights feed embed_k/linear_k: never split.  bf16x3 convs: split 2 = [cout][K] for the glds kernel
+        split = (2 if self.glds else 1) if (self.x3 and w.ndim == 4) else 0
         cin_pad = _round_up(cin, 32 if w.ndim == 4 else 4)       # conv K-tiles are 32 channels of one tap
         k_pad = _round_up(taps * cin_pad, 32)
         wt = torch.empty(k_pad // 4 * cout * 4, dtype=torch.float32, device=w.device)
@@ -281,7 +284,7 @@ class Engine:
                        wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad,
                        zeros=self.zeros.data_ptr() if getattr(self, "zeros", None) is not None else None, zeros_bytes=65536, cout=W.cout,
                        out=out.ptr if out is not None else None, out_s8=out_s8.ptr if out_s8 is not None else None,
-                       out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, epi=epi,
+                       out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, kernel=1 if (prec and self.glds) else 0, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
                        res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip)
         self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}")
