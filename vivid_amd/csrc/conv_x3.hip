@@ -191,7 +191,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
 // Entry used by vh_conv for prec == VH_PREC_BF16X3 && kernel == VH_CONV_GLDS (arguments already validated).
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
-    const bool wide = a.cout % 256 == 0;                   // 256x256 tile; otherwise 256x128
+    // 256x256 tiles when Cout allows it and the grid still gives every CU (256) a workgroup; otherwise 256x128
+    const bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
     const int BN = wide ? 256 : 128;
     const long long MT = (M + 255) / 256, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
