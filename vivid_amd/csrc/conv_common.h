@@ -70,6 +70,81 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvK& a, const f32x16 
     }
 }
 
+// Epilogue of one 32x32 accumulator tile, transposed through a per-wave LDS patch so that every lane handles
+// 4 consecutive output channels of one pixel: residual / cvec loads and the fp32 / S8 stores are 16-byte (8-byte for
+// the bf16 halves) accesses, 8 lanes per 128-byte line, instead of 4-byte accesses - a quarter of the memory
+// instructions (the accumulator-layout epilogue is store-issue bound).  `patch`: 32 x 36 floats owned by this wave.
+__device__ __forceinline__ void conv_epilogue_tile_lds(const ConvK& a, const f32x16 accv, int row0, int col0,
+                                                        float* patch, int lane) {
+    constexpr int LD = 36;
+    const int lr = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hh) * LD + lr] = accv[r];
+    // (same wave wrote and reads: the compiler orders the ds_read behind the ds_writes with lgkmcnt)
+    const int cg = lane & 7, rsub = lane >> 3;
+    const int gn = col0 + 4 * cg;
+    const int Hr = a.h >> 1, Wr = a.w >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = rsub + 8 * i;
+        const float4 v = *reinterpret_cast<const float4*>(&patch[rl * LD + 4 * cg]);
+        const int gm = row0 + rl;
+        if (gm >= a.M || gn >= a.cout) continue;
+        float y[4] = {v.x, v.y, v.z, v.w};
+        const bool full = gn + 3 < a.cout;
+        if (a.epi == VH_EPI_SCALE_SILU) {
+            const int img = gm / a.HW;
+            const float* cp = a.cvec + (size_t)img * a.cvec_ld + gn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (full || gn + j < a.cout) y[j] = mp_silu_dev(y[j] * cp[j]);
+        } else if (a.epi == VH_EPI_MPSUM) {
+            size_t rrow = (size_t)gm;
+            if (a.res_up) {
+                const int img = gm / a.HW;
+                const int rem = gm - img * a.HW;
+                const int yy = rem / a.w, xx = rem - yy * a.w;
+                rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
+            }
+            const float* rp = a.res + rrow * a.cout + gn;
+            float rv[4];
+            if (full && (a.cout & 3) == 0) {
+                const float4 t = *reinterpret_cast<const float4*>(rp);
+                rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rv[j] = (gn + j < a.cout) ? rp[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = rv[j] * a.ta + y[j] * a.tb;
+                if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
+            }
+        }
+        if (a.out) {
+            float* op = a.out + (size_t)gm * a.cout + gn;
+            if (full && (a.cout & 3) == 0) {
+                *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (gn + j < a.cout) op[j] = y[j];
+            }
+        }
+        if (a.out_s8) {       // cout % 32 == 0 here: the 4 channels are half of one 8-channel chunk
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[j] = bf16_rn_bits(y[j]);
+                l[j] = bf16_rn_bits(y[j] - __uint_as_float(h[j] << 16));
+            }
+            unsigned short* q = a.out_s8 + ((size_t)gm * a.out_s8_c + (size_t)(gn & ~7)) * 2 + (gn & 7);
+            *reinterpret_cast<uint2*>(q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+            *reinterpret_cast<uint2*>(q + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+        }
+    }
+}
+
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
 // workgroup ids b, b+8, b+16, ... share an L2.  Give each of those 8 groups one contiguous run of tiles
 // (bijective for any grid size): adjacent pixel tiles - which re-read each other's halo rows - and the

@@ -179,11 +179,13 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         __syncthreads();                                   // ... and so has every other wave's
     }
 
+    // the loop's last barrier has retired every read of the stages: reuse sA as 8 per-wave transpose patches
+    float* patch = reinterpret_cast<float*>(&sA[0][0]) + w * (32 * 36);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-            conv_epilogue_tile(a, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32 + lr, hh);
+            conv_epilogue_tile_lds(a, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
 }
 
 }  // namespace
