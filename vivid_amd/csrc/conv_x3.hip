@@ -195,14 +195,18 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const long long M = k.M;
     // 256x256 tiles when Cout allows it and the grid still gives every CU (256) a workgroup; otherwise 256x128
     const bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
-    const int BN = wide ? 256 : 128;
-    const long long MT = (M + 255) / 256, NT = (a.cout + BN - 1) / BN;
+    // 512x128 tiles (same 128x64 wave tile as the wide config) when only the narrow N fits and M is large
+    const bool tall = !wide && ((M + 511) / 512) * ((a.cout + 127) / 128) >= 512;
+    const int BN = wide ? 256 : 128, BMt = tall ? 512 : 256;
+    const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
     k.NT = (int)NT;
     const unsigned grid = (unsigned)(MT * NT);
     const int taps = a.taps;
-    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, wide, grid](hipStream_t s) -> int {
-        if (taps == 9 && wide) hipLaunchKernelGGL((conv_x3_glds<9, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
+    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, wide, tall, grid](hipStream_t s) -> int {
+        if (tall && taps == 9) hipLaunchKernelGGL((conv_x3_glds<9, 4, 2, 4, 2>), dim3(grid), dim3(512), 0, s, k);
+        else if (tall) hipLaunchKernelGGL((conv_x3_glds<1, 4, 2, 4, 2>), dim3(grid), dim3(512), 0, s, k);
+        else if (taps == 9 && wide) hipLaunchKernelGGL((conv_x3_glds<9, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
         else if (taps == 9) hipLaunchKernelGGL((conv_x3_glds<9, 4, 2, 2, 2>), dim3(grid), dim3(512), 0, s, k);
         else if (wide) hipLaunchKernelGGL((conv_x3_glds<1, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
         else hipLaunchKernelGGL((conv_x3_glds<1, 4, 2, 2, 2>), dim3(grid), dim3(512), 0, s, k);
