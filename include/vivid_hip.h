@@ -271,6 +271,27 @@ typedef struct {
 } vh_warp_args;
 int vh_warp_features(vh_ctx* ctx, const vh_warp_args* a);
 
+/* ---- K17: pixel codec (training/encoders.py:58-62) ---------------------------
+ * decode=0: out_f32[i] = in_u8[i] / 127.5 - 1          (StandardRGBEncoder.encode_latents)
+ * decode=1: out_u8[i]  = uint8(clip(in_f32[i] * 127.5 + 128, 0, 255))   (StandardRGBEncoder.decode; truncation
+ *           toward zero like torch's float -> uint8 cast) */
+typedef struct {
+    const void* in; void* out; size_t n; int decode;
+} vh_codec_args;
+int vh_codec(vh_ctx* ctx, const vh_codec_args* a);
+
+/* ---- add_depth (training/utils.py:129-139) ----------------------------------
+ * Appends a depth map as the last source channel: out[r] = cat(src[r] (c channels), d'), NCHW, with
+ * inv_norm=1: d' = ((1/d) / max_r(1/d) - 0.4947) / 0.2294   (per-sample max over the whole map), else d' = d.
+ * The depth map itself comes from an external monocular depth model (out of scope). */
+typedef struct {
+    const float* src; int c;          /* [rows][c][h][w] */
+    const float* depth;               /* [rows][1][h][w] */
+    int rows, h, w, inv_norm;
+    float* out;                       /* [rows][c+1][h][w] */
+} vh_add_depth_args;
+int vh_add_depth(vh_ctx* ctx, const vh_add_depth_args* a);
+
 /* ---- K16: sampler update (generate_images.py:93-94,108-109) ---------------
  * d = (x - D)/t_hat;  Euler: x_next = x + (t_next - t_hat) * d           (d_out written)
  * Heun : x_next = x + (t_next - t_hat) * (0.5*d_prev + 0.5*(x_probe - D)/t_next)

@@ -296,3 +296,25 @@ def test_sampler_step_euler_heun_guided(ctx):
                                                   d_cur=dc.data_ptr(), t_hat=t_hat, t_next=t_next, rows=B, row_mul=2, row_elems=n, x_next=xo2.data_ptr()))
     torch.cuda.synchronize()
     assert rel_l2(xo2.cpu()[::2], x2) < 1e-6
+
+
+def test_codec_and_add_depth():
+    """StandardRGBEncoder (training/encoders.py:58-62) and add_depth's arithmetic (training/utils.py:135-139)."""
+    import vivid_amd
+    g = torch.Generator().manual_seed(2)
+    u8 = torch.randint(0, 256, (2, 3, 16, 16), generator=g, dtype=torch.uint8)
+    enc = vivid_amd.StandardRGBEncoder()
+    lat = enc.encode_latents(u8.cuda())
+    assert torch.equal(lat.cpu(), R.encode_latents(u8))
+    assert torch.equal(enc.decode(lat).cpu(), u8)
+    x = torch.randn(2, 3, 16, 16, generator=g) * 1.5          # values outside [-1,1] exercise the clip
+    assert torch.equal(enc.decode(x.cuda()).cpu(), R.decode_latents(x))
+    src = torch.rand(3, 3, 8, 8, generator=g) * 2 - 1
+    depth = torch.rand(3, 1, 8, 8, generator=g) * 4 + 0.5
+    inv = 1 / depth
+    inv = inv / inv.amax((1, 2, 3), keepdim=True)
+    ref = torch.cat([src, (inv - 0.4947) / 0.2294], dim=1)
+    got = vivid_amd.add_depth(depth.cuda(), src.cuda(), inv_norm=True)
+    assert rel_l2(got.cpu(), ref) < 1e-6
+    got2 = vivid_amd.add_depth(depth.cuda(), src.cuda(), inv_norm=False)
+    assert torch.equal(got2.cpu(), torch.cat([src, depth], dim=1))

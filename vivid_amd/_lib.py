@@ -97,6 +97,15 @@ class WarpArgs(C.Structure):
                 ("rows", C.c_int), ("s", C.c_int), ("grid_feat", C.c_void_p), ("warp_feat", C.c_void_p)]
 
 
+class CodecArgs(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("n", C.c_size_t), ("decode", C.c_int)]
+
+
+class AddDepthArgs(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("c", C.c_int), ("depth", C.c_void_p), ("rows", C.c_int), ("h", C.c_int),
+                ("w", C.c_int), ("inv_norm", C.c_int), ("out", C.c_void_p)]
+
+
 class SamplerStepArgs(C.Structure):
     _fields_ = [("x_hat", C.c_void_p), ("x_probe", C.c_void_p), ("d_cond", C.c_void_p), ("d_ref", C.c_void_p),
                 ("guidance", C.c_float), ("d_cur", C.c_void_p), ("t_hat", C.c_float), ("t_next", C.c_float),
@@ -109,7 +118,7 @@ OPS = {
     "vh_qkv_split": QkvSplitArgs, "vh_attention": AttentionArgs, "vh_embed": EmbedArgs,
     "vh_qkv_split_x3": QkvSplitArgs, "vh_attention_x3": AttentionArgs,
     "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
-    "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs,
+    "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs, "vh_codec": CodecArgs, "vh_add_depth": AddDepthArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
 CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",

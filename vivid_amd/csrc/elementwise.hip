@@ -364,6 +364,43 @@ __global__ __launch_bounds__(256) void sampler_step_k(vh_sampler_step_args a, lo
     for (int j = 0; j < a.row_mul; ++j) a.x_next[xi + (size_t)j * a.row_elems] = xn;
 }
 
+// ---------------------------------------------------------------- pixel codec
+__global__ __launch_bounds__(256) void codec_k(vh_codec_args a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    if (!a.decode) {
+        static_cast<float*>(a.out)[i] = static_cast<const unsigned char*>(a.in)[i] / 127.5f - 1.0f;
+    } else {
+        const float v = fminf(fmaxf(static_cast<const float*>(a.in)[i] * 127.5f + 128.0f, 0.0f), 255.0f);
+        static_cast<unsigned char*>(a.out)[i] = (unsigned char)v;
+    }
+}
+
+// ---------------------------------------------------------------- add_depth: one workgroup per sample
+__global__ __launch_bounds__(256) void add_depth_k(vh_add_depth_args a) {
+    __shared__ float red[4];
+    const int r = blockIdx.x, t = threadIdx.x;
+    const int hw = a.h * a.w;
+    const float* d = a.depth + (size_t)r * hw;
+    float* o = a.out + (size_t)r * (a.c + 1) * hw;
+    const float* s = a.src + (size_t)r * a.c * hw;
+    for (int i = t; i < a.c * hw; i += 256) o[i] = s[i];
+    float mx = -INFINITY;
+    if (a.inv_norm) {
+        for (int i = t; i < hw; i += 256) mx = fmaxf(mx, 1.0f / d[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        if ((t & 63) == 0) red[t >> 6] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    }
+    for (int i = t; i < hw; i += 256) {
+        float v = d[i];
+        if (a.inv_norm) v = ((1.0f / v) / mx - 0.4947f) / 0.2294f;
+        o[(size_t)a.c * hw + i] = v;
+    }
+}
+
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -498,6 +535,27 @@ extern "C" int vh_warp_features(vh_ctx* ctx, const vh_warp_args* p) {
     return vh_dispatch(ctx, VH_TAG_WARP, 0.0, 8.0 * (double)total, [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(warp_features_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("warp_features_k");
+    });
+}
+
+extern "C" int vh_codec(vh_ctx* ctx, const vh_codec_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_codec: null args");
+    const vh_codec_args a = *p;
+    VH_REQUIRE(a.in && a.out && a.n > 0, "vh_codec: bad arguments");
+    return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 5.0 * (double)a.n, [a](hipStream_t s) -> int {
+        hipLaunchKernelGGL(codec_k, dim3(blocks_for((long long)a.n, 256)), dim3(256), 0, s, a);
+        return vh_check_launch("codec_k");
+    });
+}
+
+extern "C" int vh_add_depth(vh_ctx* ctx, const vh_add_depth_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_add_depth: null args");
+    const vh_add_depth_args a = *p;
+    VH_REQUIRE(a.src && a.depth && a.out, "vh_add_depth: null tensor");
+    VH_REQUIRE(a.rows > 0 && a.c > 0 && a.h > 0 && a.w > 0, "vh_add_depth: bad geometry");
+    return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 8.0 * (double)a.rows * (a.c + 1) * a.h * a.w, [a](hipStream_t s) -> int {
+        hipLaunchKernelGGL(add_depth_k, dim3(a.rows), dim3(256), 0, s, a);
+        return vh_check_launch("add_depth_k");
     });
 }
 
