@@ -42,6 +42,17 @@ WORKLOADS = {
 }
 
 
+def measured_traffic(precision):
+    """HBM bytes per launch per kernel family from the committed rocprofv3 PMC summary of THIS command
+    (profiles/, collected in separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md).  None when no summary for this precision is committed."""
+    path = os.path.join(ROOT, "profiles", f"traffic_c2_{precision}.json")
+    if not os.path.exists(path):
+        return {}, None
+    d = json.load(open(path))
+    return {k: v["hbm_bytes_per_launch"] for k, v in d.get("families", {}).items()}, os.path.relpath(path, ROOT)
+
+
 def rho_schedule(num_steps=32, sigma_min=0.002, sigma_max=80.0, rho=7.0):
     idx = torch.arange(num_steps, dtype=torch.float32)
     t = (sigma_max ** (1 / rho) + idx / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
@@ -210,8 +221,10 @@ def main():
                 peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
             else:
                 achieved, peak, unit = kd["gbs"], PEAK_HBM_GBS, "GB/s"
+            traffic, tsrc = measured_traffic(args.precision) if args.workload == "c2" and not args.batch else ({}, None)
             out["roofline"] = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": achieved, "peak": peak,
-                               "unit": unit, "frac": achieved / peak, "traffic": None,
+                               "unit": unit, "frac": achieved / peak, "traffic": traffic.get(dom), "traffic_source": tsrc,
+                               "algorithmic_bytes_per_launch": vd["bytes"] / vd["launches"],
                                "avg_launch_ms": vd["ms"] / vd["launches"], "launches": vd["launches"],
                                "algorithmic_per_launch": (vd["flops"] if mfma_bound else vd["bytes"]) / vd["launches"],
                                "share_of_step": kd["ms_per_step"] / out["ms_per_step"],

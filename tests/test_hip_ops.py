@@ -204,11 +204,12 @@ def test_qkv_split_and_attention(ctx, x3, b, heads, s, kl, d, nz):
     assert rel_l2(out.cpu(), ref.permute(0, 2, 1)) < (1e-4 if x3 else 2e-5)
 
 
-def test_attention_softmax_rescale_branch(ctx):
+@pytest.mark.parametrize("s", [64, 256])
+def test_attention_softmax_rescale_branch(ctx, s):
     """Force the running-max update late in the key sequence: one key matches one query far better
     than everything before it (cdna guide rule 26: a rare data-dependent branch needs its own test)."""
     from vivid_amd import _lib as L
-    b, heads, s, kl, d = 1, 1, 64, 512, 64
+    b, heads, kl, d = 1, 1, 512, 64          # s=256 runs the software-pipelined x3 kernel, s=64 the plain one
     g = torch.Generator().manual_seed(99)
     q = torch.randn(b, heads, s, d, generator=g) * 0.05
     k = torch.randn(b, heads, kl, d, generator=g) * 0.05

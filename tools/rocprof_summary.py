@@ -13,8 +13,8 @@ import json
 import os
 import re
 
-FAMILIES = [("conv_igemm_f32<9>", "conv3x3"), ("conv_igemm_f32<1>", "conv1x1"), ("conv_igemm_bf16x3<9>", "conv3x3"),
-            ("conv_igemm_bf16x3<1>", "conv1x1"), ("attn_fwd", "attention"),
+FAMILIES = [("conv_igemm_f32<9>", "conv3x3"), ("conv_igemm_f32<1>", "conv1x1"), ("conv_igemm<9", "conv3x3"),
+            ("conv_igemm<1", "conv1x1"), ("conv_x3_glds<9", "conv3x3"), ("conv_x3_glds<1", "conv1x1"), ("attn_fwd", "attention"),
             ("pixnorm_k", "pixnorm"), ("qkv_split_k", "qkv_split"), ("embed_k", "embed"), ("linear_k", "embed"),
             ("assemble_k", "assemble"), ("precond_out_k", "assemble"), ("sampler_step_k", "sampler"),
             ("prep_weight_k", "prep"), ("warp_features_k", "warp"), ("split_k", "split")]
@@ -63,7 +63,18 @@ def main():
             r["hbm_read_mb_per_call"] = 2 * p["FETCH_SIZE"]["kib_per_call"] * 1024 / 1e6      # gfx950 x2 correction
         if "WRITE_SIZE" in p:
             r["hbm_write_mb_per_call"] = p["WRITE_SIZE"]["kib_per_call"] * 1024 / 1e6
-    out = dict(note=a.note, kernels=[r for r in rows if r["pct"] >= 0.001])
+    fam = {}
+    for r in rows:
+        f = next((v for k, v in FAMILIES if k in r["kernel"]), None)
+        if f is None or "hbm_read_mb_per_call" not in r:
+            continue
+        e = fam.setdefault(f, dict(calls=0, bytes=0.0, ms=0.0))
+        e["calls"] += r["calls"]
+        e["bytes"] += r["calls"] * (r["hbm_read_mb_per_call"] + r.get("hbm_write_mb_per_call", 0.0)) * 1e6
+        e["ms"] += r["total_ms"]
+    traffic = {f: dict(hbm_bytes_per_launch=e["bytes"] / e["calls"], avg_launch_ms=e["ms"] / e["calls"], launches=e["calls"])
+               for f, e in fam.items()}
+    out = dict(note=a.note, kernels=[r for r in rows if r["pct"] >= 0.001], families=traffic)
     os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
     json.dump(out, open(a.out + ".json", "w"), indent=1)
     with open(a.out + ".md", "w") as f:

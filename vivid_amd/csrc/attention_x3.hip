@@ -274,6 +274,258 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Software-pipelined form for long sequences (8 waves, >= 2 key tiles).  One step = one 32-key sub-tile:
+//     S_next = K(j+1) Q^T - m        12 MFMAs   } one scheduling region: the matrix pipe works on the NEXT
+//     P      = exp2(S_cur), l += ..  ~100 VALU  } sub-tile's logits while the VALU finishes the current softmax
+//     O     += V(j)^T P              12 MFMAs
+// (in the plain kernel above the two waves of a SIMD run the same QK -> softmax -> PV sequence in lock step,
+// re-aligned by the barrier every tile, so MFMA time and VALU time add up instead of overlapping).
+// K lives in a 3-slot LDS ring (tile t+1's first sub-tile is needed while tile t is still being consumed),
+// V in 2 slots; K[t+2] and V[t+1] are fetched to registers during tile t and stored before its closing barrier.
+// Key masking of a ragged last tile is done through the MFMA's initial accumulator (-inf + x = -inf).
+template <int D>
+__global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
+    constexpr int NT = 512;
+    constexpr int KU = D / 4;
+    constexpr int K_UNITS = KU * KT, V_UNITS = D * 2 * (KT / 8);
+    __shared__ uint4 sK[3][K_UNITS];
+    __shared__ uint4 sV[2][V_UNITS];
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
+    const int bh = blockIdx.y;
+    const int b = bh / a.heads, hd = bh - b * a.heads;
+    const int qrow = blockIdx.x * 256 + wv * 32 + lr;
+
+    bf16x8 qh[D / 16], ql[D / 16];
+    {
+        const float* Qb = a.q + ((size_t)bh * a.s + (qrow < a.s ? qrow : 0)) * D;
+#pragma unroll
+        for (int sl = 0; sl < D / 16; ++sl) {
+            float v[8];
+            const float4 p0 = *reinterpret_cast<const float4*>(Qb + sl * 16 + hh * 8);
+            const float4 p1 = *reinterpret_cast<const float4*>(Qb + sl * 16 + hh * 8 + 4);
+            v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+            if (qrow >= a.s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            split8(v, qh[sl], ql[sl]);
+        }
+    }
+    f32x16 oacc[D / 32];
+#pragma unroll
+    for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
+    float mrow = 0.f;
+    float lsum = a.n_zero;
+
+    constexpr int KPT = K_UNITS / NT, VPT = V_UNITS / NT;
+    const uint4* kp[KPT];
+    const uint4* vp[VPT];
+    int ksl[KPT], vsl[VPT], kkey[KPT], vku[VPT];
+    {
+        const uint4* Kb = a.k + (size_t)bh * a.klp * KU;
+        const uint4* Vb = a.vt + (size_t)bh * D * 2 * (a.klp / 8);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = t + i * NT;
+            const int key = idx / KU, u = idx - key * KU;
+            kp[i] = Kb + (size_t)key * KU + u;
+            ksl[i] = u * KT + (key ^ (u & 7));
+            kkey[i] = key;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = t + i * NT;
+            const int row = idx >> 3, ku = idx & 7;
+            const int d = row >> 1, hl = row & 1;
+            vp[i] = Vb + (size_t)row * (a.klp / 8) + ku;
+            vsl[i] = d * 16 + ((hl * 8 + ku) ^ (d & 15));
+            vku[i] = ku;
+        }
+    }
+    uint4 rk[KPT], rv[VPT];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto loadK = [&]() {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) { rk[i] = *kp[i]; kp[i] += KT * KU; }
+    };
+    auto loadV = [&]() {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { rv[i] = *vp[i]; vp[i] += KT / 8; }
+    };
+    auto storeK = [&](int slot, int k0, bool tail) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            uint4 v = rk[i];
+            if (tail && k0 + kkey[i] >= a.kl) v = zero4;
+            sK[slot][ksl[i]] = v;
+        }
+    };
+    auto storeV = [&](int slot, int k0, bool tail) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            uint4 v = rv[i];
+            if (tail && k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {
+                unsigned short* e = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pos = vku[i] * 8 + j;
+                    const int key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+                    if (k0 + key >= a.kl) e[j] = 0;
+                }
+            }
+            sV[slot][vsl[i]] = v;
+        }
+    };
+
+    const int ntiles = (a.kl + KT - 1) / KT;
+    const bool ragged = (a.kl % KT) != 0;
+    auto is_tail = [&](int tile) { return ragged && tile == ntiles - 1; };
+
+    // initial accumulator of a sub-tile's logits: -m, or -inf for keys past the end of a ragged last tile
+    auto init_s = [&](f32x16& sacc, int k0, int ks, bool tail) {
+        if (tail) {
+            const int kbase = k0 + ks * 32 + 4 * hh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = (kbase + (r & 3) + 8 * (r >> 2) < a.kl) ? -mrow : -INFINITY;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = -mrow;
+        }
+    };
+    auto qk = [&](f32x16& sacc, int slot, int ks) {
+        const int key = ks * 32 + lr;
+#pragma unroll
+        for (int sl = 0; sl < D / 16; ++sl) {
+            const int uh = (sl * 2 + hh) * 2, ul = uh + 1;
+            const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&sK[slot][uh * KT + (key ^ (uh & 7))]);
+            const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(&sK[slot][ul * KT + (key ^ (ul & 7))]);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl_, qh[sl], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[sl], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[sl], sacc, 0, 0, 0);
+        }
+    };
+
+    f32x16 scur, snext;
+    bool first = !(a.n_zero > 0.f);
+
+    // one pipeline step: finish sub-tile (vslot, vks) whose logits are in scur; start the next one if any
+    auto step = [&](int vslot, int vks, bool has_next, int nslot, int nks, int nk0, bool ntail) {
+        // region A: row max of the current logits (scur = s - m), rare raise of the running max
+        float mx = scur[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (first) {                                        // no max yet: adopt this sub-tile's (O and l are still 0)
+            first = false;
+            mrow = mx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scur[r] -= mx;
+        } else if (__any(mx > RESCALE_THR)) {
+            const float dm = fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-dm);
+            lsum *= alpha;
+            mrow += dm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scur[r] -= dm;
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+        }
+        if (has_next) init_s(snext, nk0, nks, ntail);
+        // region B: next sub-tile's QK^T on the matrix pipe, this sub-tile's exp / sum / bf16 split on the VALU
+        if (has_next) qk(snext, nslot, nks);
+        float rs = 0.f;
+        bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pv[j] = __builtin_amdgcn_exp2f(scur[8 * s2 + j]);
+                rs += pv[j];
+            }
+            split8(pv, ph[s2], pl[s2]);
+        }
+        rs += __shfl_xor(rs, 32);
+        lsum += rs;
+        // O^T += V^T P^T
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int kuh = vks * 4 + s2 * 2 + hh;
+#pragma unroll
+            for (int dt = 0; dt < D / 32; ++dt) {
+                const int d = dt * 32 + lr;
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(&sV[vslot][d * 16 + (kuh ^ (d & 15))]);
+                const bf16x8 vl = *reinterpret_cast<const bf16x8*>(&sV[vslot][d * 16 + ((8 + kuh) ^ (d & 15))]);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph[s2], oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl[s2], oacc[dt], 0, 0, 0);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], oacc[dt], 0, 0, 0);
+            }
+        }
+        if (has_next) scur = snext;
+    };
+
+    // prologue: K[0], V[0], K[1] in LDS; logits of sub-tile 0
+    loadK(); loadV();
+    storeK(0, 0, is_tail(0)); storeV(0, 0, is_tail(0));
+    if (ntiles > 1) { loadK(); storeK(1, KT, is_tail(1)); }
+    __syncthreads();
+    init_s(scur, 0, 0, is_tail(0));
+    qk(scur, 0, 0);
+
+    int ks0 = 0, ks1 = 1, ks2 = 2;                          // K slots of tiles t, t+1, t+2
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT;
+        const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
+        if (more2) loadK();
+        if (more1) loadV();
+        step(tile & 1, 0, true, ks0, 1, k0, is_tail(tile));
+        step(tile & 1, 1, more1, ks1, 0, k0 + KT, is_tail(tile + 1));
+        if (more2) storeK(ks2, k0 + 2 * KT, is_tail(tile + 2));
+        if (more1) storeV((tile + 1) & 1, k0 + KT, is_tail(tile + 1));
+        __syncthreads();
+        const int tmp = ks0; ks0 = ks1; ks1 = ks2; ks2 = tmp;
+    }
+
+    if (qrow < a.s && a.out_s8) {
+        const float inv = 1.0f / lsum;
+        unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + (((size_t)b * a.s + qrow) * a.c + hd * D) * 2;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned h[4], lo4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = oacc[dt][4 * g + j] * inv;
+                    h[j] = bf16_rn_bits(v);
+                    lo4[j] = bf16_rn_bits(v - __uint_as_float(h[j] << 16));
+                }
+                unsigned short* q8 = op + (dt * 32 + 8 * g) * 2 + 4 * hh;
+                *reinterpret_cast<uint2*>(q8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(q8 + 8) = make_uint2(lo4[0] | (lo4[1] << 16), lo4[2] | (lo4[3] << 16));
+            }
+    } else if (qrow < a.s) {
+        const float inv = 1.0f / lsum;
+        float* op = a.out + ((size_t)b * a.s + qrow) * a.c + hd * D;
+#pragma unroll
+        for (int dt = 0; dt < D / 32; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 o;
+                o.x = oacc[dt][4 * g + 0] * inv; o.y = oacc[dt][4 * g + 1] * inv;
+                o.z = oacc[dt][4 * g + 2] * inv; o.w = oacc[dt][4 * g + 3] * inv;
+                *reinterpret_cast<float4*>(op + dt * 32 + 8 * g + 4 * hh) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // q/k/v split + head norm writing the operand formats above (view/normalize/unbind of
 // training/models.py:192-194, :279-293; sequence concat :296-297 via koff).
 // One workgroup = one (row, head) x 64 consecutive pixels.
@@ -394,12 +646,15 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     // One 8-wave workgroup per CU for long sequences (two independent 4-wave workgroups per CU measured 2.4x
     // slower: every workgroup stages its own copy of the K/V stream).
     const int nw = a.s > 128 ? 8 : 4;
+    static const bool use_pipe = !(getenv("VIVID_ATTN_PIPE") && atoi(getenv("VIVID_ATTN_PIPE")) == 0);
+    const bool pipe = use_pipe && nw == 8 && a.kl > KT && a.d == 64;   // (the D=32 instantiation spills its accumulators)
     const dim3 grid((a.s + nw * 32 - 1) / (nw * 32), a.b * a.heads);
     const double bhd = (double)a.b * a.heads;
     const double flops = 4.0 * bhd * a.s * a.kl * a.d;
     const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);
-    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, grid](hipStream_t s) -> int {
-        if (d == 64 && nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 8>), grid, dim3(512), 0, s, k);
+    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, grid](hipStream_t s) -> int {
+        if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
+        else if (d == 64 && nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 8>), grid, dim3(512), 0, s, k);
         else if (d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 4>), grid, dim3(256), 0, s, k);
         else if (nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<32, 8>), grid, dim3(512), 0, s, k);
         else hipLaunchKernelGGL((attn_fwd_bf16x3<32, 4>), grid, dim3(256), 0, s, k);
