@@ -5,6 +5,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace vhconv {
 
@@ -74,6 +75,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvK& a, const f32x16 
 // 4 consecutive output channels of one pixel: residual / cvec loads and the fp32 / S8 stores are 16-byte (8-byte for
 // the bf16 halves) accesses, 8 lanes per 128-byte line, instead of 4-byte accesses - a quarter of the memory
 // instructions (the accumulator-layout epilogue is store-issue bound).  `patch`: 32 x 36 floats owned by this wave.
+__device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane);
+
 __device__ __forceinline__ void conv_epilogue_tile_lds(const ConvK& a, const f32x16 accv, int row0, int col0,
                                                         float* patch, int lane) {
     constexpr int LD = 36;
@@ -81,6 +84,28 @@ __device__ __forceinline__ void conv_epilogue_tile_lds(const ConvK& a, const f32
 #pragma unroll
     for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hh) * LD + lr] = accv[r];
     // (same wave wrote and reads: the compiler orders the ds_read behind the ds_writes with lgkmcnt)
+    conv_epilogue_patch(a, row0, col0, patch, lane);
+}
+
+// Same for a 32x32 block held as 2x2 accumulator tiles of v_mfma_f32_16x16x32 (C/D map: column = lane&15,
+// row = 4*(lane>>4) + reg).
+__device__ __forceinline__ void conv_epilogue_tiles16_lds(const ConvK& a, const f32x4 t00, const f32x4 t01, const f32x4 t10,
+                                                           const f32x4 t11, int row0, int col0, float* patch, int lane) {
+    constexpr int LD = 36;
+    const int c = lane & 15, rb = (lane >> 4) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        patch[(rb + r) * LD + c] = t00[r];
+        patch[(rb + r) * LD + 16 + c] = t01[r];
+        patch[(16 + rb + r) * LD + c] = t10[r];
+        patch[(16 + rb + r) * LD + 16 + c] = t11[r];
+    }
+    conv_epilogue_patch(a, row0, col0, patch, lane);
+}
+
+// Read-out of a 32 x 36-float patch: every lane handles 4 consecutive output channels of one pixel.
+__device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane) {
+    constexpr int LD = 36;
     const int cg = lane & 7, rsub = lane >> 3;
     const int gn = col0 + 4 * cg;
     const int Hr = a.h >> 1, Wr = a.w >> 1;

@@ -14,6 +14,7 @@
 // K runs tap-major in 32-channel tiles; per tap each thread derives its 4 pixel pointers (zero page outside
 // the image).  Two LDS stages; the loads of tile t+1 are in flight during the MFMAs of tile t.
 #include "conv_common.h"
+#include <cstdlib>
 
 namespace {
 using namespace vhconv;
@@ -43,7 +44,11 @@ __device__ __forceinline__ void wait_dma() {
 #endif
 }
 
-template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI>
+// M16 = true uses v_mfma_f32_16x16x32_bf16 (one MFMA covers the whole 32-channel K-tile) instead of two
+// 16-deep v_mfma_f32_32x32x16_bf16 slabs: same cycles per FLOP, but the chip holds a higher clock on the 16x16
+// shape (MI355X_MICROARCH.md, DVFS give-back item 7).  The LDS unit order is then hl*4 + chunk (conflict-free
+// for the 16-row operand reads) instead of chunk*2 + hl; only the source-side mapping of the DMA changes.
+template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16>
 __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     static_assert(WAVES_M * WAVES_N == 8, "8 waves");
     constexpr int BM = WAVES_M * MI * 32, BN = WAVES_N * NI * 32;
@@ -61,7 +66,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     // slot (round j, wave w, lane l) = j*512 + w*64 + l  ->  row = slot>>3 = j*64 + w*8 + (l>>3), unit' = l&7.
     // (row>>1)&7 = ((w&1)<<2) | (l>>4) for every round, so a thread fetches the same unit u of RA (RB) rows.
     const int rsub = w * 8 + (l >> 3);
-    const int u = (l & 7) ^ (((w & 1) << 2) | (l >> 4));
+    const int uslot = (l & 7) ^ (((w & 1) << 2) | (l >> 4));          // logical unit held by this lane's LDS slot
+    const int u = M16 ? ((uslot & 3) * 2 + (uslot >> 2)) : uslot;      // ... and where it sits in the S8 row
     const int Hs = a.up ? (a.h >> 1) : a.h, Ws = a.up ? (a.w >> 1) : a.w;
     int py[RA], px[RA], pbase[RA];
     bool pv[RA];
@@ -117,42 +123,83 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         }
     };
 
-    f32x16 acc[MI][NI];
+    f32x16 acc[M16 ? 1 : MI][M16 ? 1 : NI];
+    f32x4 acc16[M16 ? MI * 2 : 1][M16 ? NI * 2 : 1];
+    if constexpr (M16) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI * 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+            for (int j = 0; j < NI * 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     const int wm = w / WAVES_N, wn = w % WAVES_N;
     const int swz = (lr >> 1) & 7;                         // (row>>1)&7 of every row this lane reads
     const int arow = (wm * MI * 32 + lr) * 8, brow = (wn * NI * 32 + lr) * 8;
+    // 16x16x32: lane (row = l&15, kg = l>>4) supplies k = 8kg..8kg+7 = chunk kg of the K-tile
+    const int l15 = l & 15, kg = l >> 4, swz16 = l15 >> 1;
+    const int arow16 = (wm * MI * 32 + l15) * 8, brow16 = (wn * NI * 32 + l15) * 8;
+    const int u16h = kg ^ swz16, u16l = (4 + kg) ^ swz16;
 
     auto compute = [&](int st) {
+        if constexpr (M16) {
+            bf16x8 bh[NI * 2], bl[NI * 2];
 #pragma unroll
-        for (int sl = 0; sl < BK / 16; ++sl) {
-            // 32x32x16 bf16: lane (row = l&31, h = l>>5) supplies k = 8h..8h+7 of the slab = chunk 2*sl + h
-            const int uh = ((sl * 2 + hh) * 2) ^ swz, ul = ((sl * 2 + hh) * 2 + 1) ^ swz;
-            bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[st][arow + mi * 256 + uh]);
-                al[mi] = *reinterpret_cast<const bf16x8*>(&sA[st][arow + mi * 256 + ul]);
+            for (int j = 0; j < NI * 2; ++j) {
+                bh[j] = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
+                bl[j] = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
             }
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                bh[ni] = *reinterpret_cast<const bf16x8*>(&sB[st][brow + ni * 256 + uh]);
-                bl[ni] = *reinterpret_cast<const bf16x8*>(&sB[st][brow + ni * 256 + ul]);
-            }
+            for (int half = 0; half < 2; ++half) {             // A fragments in two batches: 64 instead of 96 registers
+                bf16x8 ah[MI], al[MI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int i = 0; i < MI; ++i) {
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&sA[st][arow16 + (half * MI + i) * 128 + u16h]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&sA[st][arow16 + (half * MI + i) * 128 + u16l]);
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI * 2; ++j) {
+                        f32x4& c = acc16[half * MI + i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < BK / 16; ++sl) {
+                // 32x32x16 bf16: lane (row = l&31, h = l>>5) supplies k = 8h..8h+7 of the slab = chunk 2*sl + h
+                const int uh = ((sl * 2 + hh) * 2) ^ swz, ul = ((sl * 2 + hh) * 2 + 1) ^ swz;
+                bf16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    ah[mi] = *reinterpret_cast<const bf16x8*>(&sA[st][arow + mi * 256 + uh]);
+                    al[mi] = *reinterpret_cast<const bf16x8*>(&sA[st][arow + mi * 256 + ul]);
+                }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    bh[ni] = *reinterpret_cast<const bf16x8*>(&sB[st][brow + ni * 256 + uh]);
+                    bl[ni] = *reinterpret_cast<const bf16x8*>(&sB[st][brow + ni * 256 + ul]);
                 }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    }
+            }
         }
     };
 
@@ -185,7 +232,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-            conv_epilogue_tile_lds(a, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
+            if constexpr (M16)
+                conv_epilogue_tiles16_lds(a, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
+                                          acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
+            else
+                conv_epilogue_tile_lds(a, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
 }
 
 }  // namespace
@@ -203,13 +254,21 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     k.NT = (int)NT;
     const unsigned grid = (unsigned)(MT * NT);
     const int taps = a.taps;
-    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, wide, tall, grid](hipStream_t s) -> int {
-        if (tall && taps == 9) hipLaunchKernelGGL((conv_x3_glds<9, 4, 2, 4, 2>), dim3(grid), dim3(512), 0, s, k);
-        else if (tall) hipLaunchKernelGGL((conv_x3_glds<1, 4, 2, 4, 2>), dim3(grid), dim3(512), 0, s, k);
-        else if (taps == 9 && wide) hipLaunchKernelGGL((conv_x3_glds<9, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
-        else if (taps == 9) hipLaunchKernelGGL((conv_x3_glds<9, 4, 2, 2, 2>), dim3(grid), dim3(512), 0, s, k);
-        else if (wide) hipLaunchKernelGGL((conv_x3_glds<1, 2, 4, 4, 2>), dim3(grid), dim3(512), 0, s, k);
-        else hipLaunchKernelGGL((conv_x3_glds<1, 4, 2, 2, 2>), dim3(grid), dim3(512), 0, s, k);
+    static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
+    const int cfg = tall ? 2 : wide ? 1 : 0;
+    const bool use16 = m16;
+    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, use16, grid](hipStream_t s) -> int {
+#define VH_LAUNCH(T, WM, WN, MI_, NI_, M16_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, M16_>), dim3(grid), dim3(512), 0, s, k)
+#define VH_LAUNCH_CFG(T, M16_)                                  \
+        do {                                                    \
+            if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, M16_);       \
+            else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, M16_);  \
+            else VH_LAUNCH(T, 4, 2, 2, 2, M16_);                \
+        } while (0)
+        if (taps == 9) { if (use16) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
+        else { if (use16) VH_LAUNCH_CFG(1, true); else VH_LAUNCH_CFG(1, false); }
+#undef VH_LAUNCH_CFG
+#undef VH_LAUNCH
         return vh_check_launch("conv_x3_glds");
     });
 }
