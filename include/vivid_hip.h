@@ -292,6 +292,18 @@ typedef struct {
 } vh_add_depth_args;
 int vh_add_depth(vh_ctx* ctx, const vh_add_depth_args* a);
 
+/* ---- bilinear resize of NCHW fp32 images (the SR hand-off of generate_images.py:299-302,322) -----------
+ * torchvision.transforms.functional.resize on tensors = F.interpolate(mode="bilinear", align_corners=False,
+ * antialias=...): source coordinate (i+0.5)*scale-0.5; with antialias and scale > 1 the triangle filter is widened
+ * to `scale` (aten upsample_bilinear2d_aa); weights are normalised per output pixel. */
+typedef struct {
+    const float* in; float* out;
+    int planes;            /* rows * channels */
+    int hin, win, hout, wout;
+    int antialias;
+} vh_resize_args;
+int vh_resize_bilinear(vh_ctx* ctx, const vh_resize_args* a);
+
 /* ---- K16: sampler update (generate_images.py:93-94,108-109) ---------------
  * d = (x - D)/t_hat;  Euler: x_next = x + (t_next - t_hat) * d           (d_out written)
  * Heun : x_next = x + (t_next - t_hat) * (0.5*d_prev + 0.5*(x_probe - D)/t_next)

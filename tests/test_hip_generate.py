@@ -1,0 +1,101 @@
+"""GPU: the sampling driver (vivid_amd.generate, mirror of generate_images.py:139-343) and the bilinear resize it uses."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vivid_ref as R
+from tests.conftest import rel_l2
+from tests.golden.cases import CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("hin,hout,aa", [(8, 32, False), (8, 32, True), (32, 8, True), (32, 8, False), (24, 9, True), (64, 256, True)])
+def test_resize_matches_torch_interpolate(hin, hout, aa):
+    from vivid_amd.generate import resize
+    g = torch.Generator().manual_seed(hin * 100 + hout)
+    x = torch.randn(2, 3, hin, hin, generator=g)
+    ref = torch.nn.functional.interpolate(x, size=(hout, hout), mode="bilinear", align_corners=False, antialias=aa)
+    got = resize(x.cuda(), hout, antialias=aa)
+    assert rel_l2(got.cpu(), ref) < 1e-6
+
+
+def _mk(cfg, seed):
+    import vivid_amd
+    net = vivid_amd.NVPrecond.from_config(cfg)
+    net.load_state_dict(vivid_amd.synth_state_dict(cfg, seed=seed))
+    return net.cuda()
+
+
+def _data(n_rows, res, seed, const=False):
+    """Collated batches in DualSourceCollate's format: rows interleaved [s1, s2, s1, s2, ...]."""
+    g = torch.Generator().manual_seed(seed)
+
+    def gen():
+        while True:
+            if const:
+                one = torch.randint(0, 256, (1, 3, res, res), generator=torch.Generator().manual_seed(seed)).float()
+                src = one.repeat(n_rows, 1, 1, 1)
+                geo = torch.zeros(n_rows, 20)
+            else:
+                src = torch.randint(0, 256, (n_rows, 3, res, res), generator=g).float()
+                geo = torch.randn(n_rows, 20, generator=g)
+                geo[:, [14, 15, 18, 19]] = 0
+            yield dict(src_image=src, tgt_image=src.flip(-1), geometry=geo,
+                       sr_src_image=torch.nn.functional.interpolate(src, scale_factor=2), sr_tgt_image=torch.nn.functional.interpolate(src.flip(-1), scale_factor=2),
+                       sr_geometry=geo)
+    return gen()
+
+
+def test_driver_matches_oracle_pipeline_and_is_seed_deterministic(tmp_path):
+    import vivid_amd
+    from vivid_amd.generate import generate_images_nvs
+    case = CASES["tiny_guided"]
+    cfg, gcfg = case["cfg"], case["gcfg"]
+    net, gnet = _mk(cfg, 5), _mk(gcfg, 6)
+    seeds = [16, 17, 18]
+    kw = dict(num_steps=3, guidance=1.5)
+    # (a) one batch of 3, CPU generators so that the oracle can draw the same noise
+    out = list(generate_images_nvs(net, gnet, seeds=seeds, max_batch_size=4, data=_data(8, 16, 1), rng_device="cpu",
+                                   outdir=str(tmp_path), **kw))
+    assert len(out) == 1 and out[0].images.shape == (3, 3, 16, 16) and out[0].images.dtype == torch.uint8
+    for s in seeds:
+        for stem in ("src", "tgt", "sample"):
+            assert os.path.exists(tmp_path / f"{stem}_{s:06d}.png")
+    # oracle pipeline on the same batch
+    batch = next(_data(8, 16, 1))
+    src_u8, geo = batch["src_image"][::2][:3], batch["geometry"][::2][:3]
+    src = R.encode_latents(src_u8).repeat_interleave(2, dim=0)
+    labels = geo.repeat_interleave(2, dim=0)
+    noise = R.StackedRandomGenerator("cpu", seeds).randn([3, 3, 16, 16]).repeat_interleave(2, dim=0)
+    d = cfg.to_dict(); d.pop("use_fp16"); gd = gcfg.to_dict(); gd.pop("use_fp16")
+    onet = R.OracleNet(R.make_config(**d), vivid_amd.synth_state_dict(cfg, seed=5))
+    ognet = R.OracleNet(R.make_config(**gd), vivid_amd.synth_state_dict(gcfg, seed=6))
+    ref = R.decode_latents(R.edm_sampler(onet, src, noise, labels=labels, gnet=ognet, **kw))
+    diff = (out[0].images.cpu().int() - ref.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.01
+    # (b) a sample depends on its seed, not on how seeds are batched (constant data, device generators)
+    a = list(generate_images_nvs(net, gnet, seeds=seeds, max_batch_size=4, data=_data(8, 16, 2, const=True), **kw))
+    b = list(generate_images_nvs(net, gnet, seeds=seeds, max_batch_size=1, data=_data(8, 16, 2, const=True), **kw))
+    assert len(b) == 3
+    ia = a[0].images.cpu().int()
+    ib = torch.cat([r.images for r in b]).cpu().int()
+    assert int((ia - ib).abs().max()) <= 1
+
+
+def test_sr_cascade_runs():
+    from vivid_amd.generate import generate_images_nvs
+    base = _mk(CASES["tiny_dual"]["cfg"], 3)
+    sr_cfg = CASES["tiny_sr"]["cfg"]
+    sr = _mk(sr_cfg, 9)
+    out = list(generate_images_nvs(base, seeds=[16, 17], max_batch_size=2, data=_data(4, 16, 3), sr_model=sr, num_steps=2))
+    assert out[0].images.shape == (2, 3, 32, 32) and out[0].images.dtype == torch.uint8
+    assert out[0].noise.shape == (4, 3, 32, 32)
+
+
+def test_pickle_paths_are_refused():
+    from vivid_amd.generate import generate_images_nvs
+    with pytest.raises(NotImplementedError, match="out of scope"):
+        generate_images_nvs("https://example.invalid/vivid-base.pkl", data=[])

@@ -401,6 +401,46 @@ __global__ __launch_bounds__(256) void add_depth_k(vh_add_depth_args a) {
     }
 }
 
+// ---------------------------------------------------------------- bilinear resize (optionally anti-aliased)
+__device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
+
+__global__ __launch_bounds__(256) void resize_k(vh_resize_args a, long long total) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int xo = (int)(i % a.wout);
+    const long long r = i / a.wout;
+    const int yo = (int)(r % a.hout);
+    const long long pl = r / a.hout;
+    const float sy = (float)a.hin / a.hout, sx = (float)a.win / a.wout;
+    const float* src = a.in + (size_t)pl * a.hin * a.win;
+    float acc = 0.f;
+    if (!a.antialias) {
+        float fy = (yo + 0.5f) * sy - 0.5f, fx = (xo + 0.5f) * sx - 0.5f;
+        fy = fmaxf(fy, 0.f); fx = fmaxf(fx, 0.f);
+        const int y0 = min((int)fy, a.hin - 1), x0 = min((int)fx, a.win - 1);
+        const int y1 = min(y0 + 1, a.hin - 1), x1 = min(x0 + 1, a.win - 1);
+        const float ly = fy - y0, lx = fx - x0;
+        acc = (1.f - ly) * ((1.f - lx) * src[y0 * a.win + x0] + lx * src[y0 * a.win + x1]) +
+              ly * ((1.f - lx) * src[y1 * a.win + x0] + lx * src[y1 * a.win + x1]);
+    } else {
+        // aten upsample_bilinear2d_aa: support = max(scale, 1); taps [xmin, xmin+xsize), weights tri((j+xmin-center+0.5)/s)
+        const float supy = fmaxf(sy, 1.f), supx = fmaxf(sx, 1.f);
+        const float cy = sy * (yo + 0.5f), cx = sx * (xo + 0.5f);
+        const int ymin = max((int)(cy - supy + 0.5f), 0), ymax = min((int)(cy + supy + 0.5f), a.hin);
+        const int xmin = max((int)(cx - supx + 0.5f), 0), xmax = min((int)(cx + supx + 0.5f), a.win);
+        float wy_sum = 0.f, wx_sum = 0.f;
+        for (int y = ymin; y < ymax; ++y) wy_sum += tri((y - cy + 0.5f) / supy);
+        for (int x = xmin; x < xmax; ++x) wx_sum += tri((x - cx + 0.5f) / supx);
+        for (int y = ymin; y < ymax; ++y) {
+            const float wy = tri((y - cy + 0.5f) / supy) / wy_sum;
+            float row = 0.f;
+            for (int x = xmin; x < xmax; ++x) row += tri((x - cx + 0.5f) / supx) / wx_sum * src[y * a.win + x];
+            acc += wy * row;
+        }
+    }
+    a.out[i] = acc;
+}
+
 inline unsigned blocks_for(long long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 }  // namespace
@@ -556,6 +596,18 @@ extern "C" int vh_add_depth(vh_ctx* ctx, const vh_add_depth_args* p) {
     return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 8.0 * (double)a.rows * (a.c + 1) * a.h * a.w, [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(add_depth_k, dim3(a.rows), dim3(256), 0, s, a);
         return vh_check_launch("add_depth_k");
+    });
+}
+
+extern "C" int vh_resize_bilinear(vh_ctx* ctx, const vh_resize_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_resize_bilinear: null args");
+    const vh_resize_args a = *p;
+    VH_REQUIRE(a.in && a.out, "vh_resize_bilinear: null tensor");
+    VH_REQUIRE(a.planes > 0 && a.hin > 0 && a.win > 0 && a.hout > 0 && a.wout > 0, "vh_resize_bilinear: bad geometry");
+    const long long total = (long long)a.planes * a.hout * a.wout;
+    return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 4.0 * ((double)total + (double)a.planes * a.hin * a.win), [a, total](hipStream_t s) -> int {
+        hipLaunchKernelGGL(resize_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        return vh_check_launch("resize_k");
     });
 }
 
