@@ -64,3 +64,60 @@ def test_rank_batches_matches_reference_rule():
     # uneven: 10 seeds, max 4, 2 ranks -> 4 batches [3,3,2,2], ranks take every other one
     a = [vd.rank_batches(10, 4, world_size=2, rank=r) for r in range(2)]
     assert [len(x) for x in a[0]] == [3, 2] and [len(x) for x in a[1]] == [3, 2]
+
+
+class _Det:
+    """A stand-in feature detector (fixed random projection of the mean-pooled image)."""
+    feature_dim = 6
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(3)
+        self.w = torch.randn(3 * 4 * 4, 6, generator=g)
+
+    def __call__(self, img):
+        x = torch.nn.functional.adaptive_avg_pool2d(img.float() / 255, 4).flatten(1)
+        return x @ self.w
+
+
+def _fake_batches(n_seeds, max_batch, world, rank):
+    """What generate_images_nvs yields, without a GPU: image/tgt/src per seed are functions of the seed."""
+    out = []
+    for idx in vd.rank_batches(n_seeds, max_batch, world, rank):
+        def mk(off):
+            return torch.stack([torch.randint(0, 256, (3, 8, 8), generator=torch.Generator().manual_seed(int(i) * 7 + off)) for i in idx]) \
+                if len(idx) else torch.zeros(0, 3, 8, 8, dtype=torch.int64)
+        out.append(dict(images=mk(0), tgt=mk(1), src=mk(2)))
+    return out
+
+
+def _metrics_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    vd.init("gloo")
+    try:
+        from vivid_amd import metrics as vm
+        it = vm.calculate_stats_for_iterable_nvs(_fake_batches(12, 3, world, rank), {"fid": _Det()}, metrics=["fid", "joint_fid", "psnr"], device="cpu")
+        for r, ref in it:
+            pass
+        res = vm.calculate_metrics_from_stats_nvs(r.stats, ref.stats)
+        np.savez(os.path.join(out_dir, f"m{rank}.npz"), **{k: np.array(v) for k, v in res.items()}, n=r.num_images)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_fid_stats_two_ranks_equal_one_rank(tmp_path):
+    from vivid_amd import metrics as vm
+    world, port = 2, _free_port()
+    mp.spawn(_metrics_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    it = vm.calculate_stats_for_iterable_nvs(_fake_batches(12, 3, 1, 0), {"fid": _Det()}, metrics=["fid", "joint_fid", "psnr"], device="cpu")
+    for r, ref in it:
+        pass
+    single = vm.calculate_metrics_from_stats_nvs(r.stats, ref.stats)
+    assert set(single) == {"fid", "joint_fid", "psnr"} and single["fid"] > 0
+    for k in range(world):
+        m = np.load(tmp_path / f"m{k}.npz")
+        assert int(m["n"]) == 12
+        for key, v in single.items():
+            np.testing.assert_allclose(float(m[key]), v, rtol=1e-8, atol=1e-10)
+    # identical statistics give distance 0
+    z = vm.calculate_metrics_from_stats_nvs(r.stats, r.stats, metrics=["fid"])
+    assert abs(z["fid"]) < 1e-8
