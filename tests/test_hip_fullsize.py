@@ -102,3 +102,45 @@ def test_seeded_noise_is_placement_independent():
     a = vivid_amd.StackedRandomGenerator("cuda", [16, 17, 18]).randn([3, 3, 8, 8], device="cuda")
     b = vivid_amd.StackedRandomGenerator("cuda", [18]).randn([1, 3, 8, 8], device="cuda")
     assert torch.equal(a[2], b[0])
+
+
+def _agree(cfg, src, x, sig, geo, cond=None, tol=1e-4):
+    outs = {}
+    for prec in ("fp32", "bf16x3"):
+        net, _ = _net(cfg, 0, prec)
+        outs[prec] = net(src.cuda(), x.cuda(), sig.cuda(), geo.cuda(), None if cond is None else cond.cuda()).cpu()
+        del net
+        torch.cuda.empty_cache()
+    assert torch.isfinite(outs["bf16x3"]).all()
+    assert rel_l2(outs["bf16x3"], outs["fp32"]) < tol
+    return outs["bf16x3"]
+
+
+def test_config4_sr_built_at_1024_kernel_families_agree():
+    """BASELINE configs[3]: the SR class built with img_resolution=1024, batch 1 here."""
+    import vivid_amd
+    cfg = vivid_amd.vivid_sr(1024, noisy_sr=0.0)
+    src, img, eps, geo = _inputs(1024, 1, 11)
+    g = torch.Generator().manual_seed(4)
+    cond = torch.nn.functional.interpolate(torch.rand(1, 3, 256, 256, generator=g) * 2 - 1, size=(1024, 1024), mode="bilinear")
+    sigma = 1.5
+    out = _agree(cfg, src, img + sigma * eps, torch.full((2,), sigma), geo, cond)
+    assert out.shape == (1, 3, 1024, 1024)
+
+
+def test_config5_depth_warp_at_256_kernel_families_agree():
+    """BASELINE configs[4]: base architecture + depth-warp Fourier features at 256^2 (132-channel first convs), batch 1 here."""
+    import vivid_amd
+    from vivid_amd.geometry import compose_geometry
+    cfg = vivid_amd.vivid_base(256, warp_depth_coor=True)
+    src, img, eps, _ = _inputs(256, 1, 13, src_c=4)
+    src[:, 3] = src[:, 3] * 2 + 3                                   # depth in [1, 5]
+    g = torch.Generator().manual_seed(6)
+    th = 0.05 * torch.randn(2, generator=g)
+    Rm = torch.zeros(2, 3, 3)
+    Rm[:, 0, 0], Rm[:, 0, 2], Rm[:, 1, 1], Rm[:, 2, 0], Rm[:, 2, 2] = th.cos(), th.sin(), 1.0, -th.sin(), th.cos()
+    K = (torch.tensor([57.7, 57.7, 32.0, 32.0]) * 4).expand(2, 4)
+    geo = compose_geometry(torch.cat([Rm, 0.1 * torch.randn(2, 3, 1, generator=g)], dim=2), K, K, imsize=256)
+    sigma = 2.0
+    out = _agree(cfg, src, img + sigma * eps, torch.full((2,), sigma), geo, tol=2e-4)
+    assert out.shape == (1, 3, 256, 256)
