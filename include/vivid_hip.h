@@ -119,6 +119,8 @@ typedef struct {
     const float* zeros; size_t zeros_bytes; /* a device buffer of zeros, >= cin_pad*4 + 64 bytes: out-of-image taps and pad
                                               channels are read from it instead of being masked */
     int cout;
+    float* scratch; size_t scratch_floats; /* optional (VH_CONV_GLDS256): split-K partial sums for grids that would leave most
+                                              CUs idle; any stream-ordered temporary, reused by every call */
     float* out;                            /* [rows*h*w][cout] fp32; may be NULL if out_s8 is given */
     void* out_s8; int out_s8_c;            /* optional S8 copy of the result (cout % 32 == 0, out_s8_c == cout) */
     int prec;                              /* VH_PREC_* */

@@ -91,7 +91,8 @@ def test_base_256_kernel_families_agree_and_samples_independent():
         torch.cuda.empty_cache()
     assert outs["fp32"].shape == (2, 3, 256, 256)
     assert rel_l2(outs["bf16x3"], outs["fp32"]) < 1e-4
-    assert rel_l2(one[0], outs["bf16x3"][1]) < 1e-6          # same kernels, same per-sample arithmetic
+    # same kernels and per-sample arithmetic, up to the tile / split-K partition the launcher picks per grid size
+    assert rel_l2(one[0], outs["bf16x3"][1]) < 2e-5
     # sigma -> 0: c_skip -> 1, c_out -> sigma: D_x = x up to O(sigma)
     assert rel_l2(tiny, x[:2:2]) < 5e-3
 

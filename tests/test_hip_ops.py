@@ -42,6 +42,12 @@ def _zeros():
     return _Z["z"].data_ptr()
 
 
+def _scratch():
+    if "s" not in _Z:
+        _Z["s"] = torch.empty(1 << 22, device="cuda")
+    return _Z["s"].data_ptr()
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
@@ -68,7 +74,7 @@ def test_conv_store_fp32(ctx, rows, h, w, cin, cout, taps):
     wt, cin_pad, k_pad = _prep(ctx, wd, taps, gain=0.7)
     out = torch.empty(rows, h, w, cout, device="cuda")
     ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
-                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=out.data_ptr(),
+                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=out.data_ptr(),
                                   out_s8=None, out_s8_c=0, prec=0, kernel=0, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), _nhwc(ref)) < 2e-5
@@ -97,7 +103,7 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec, KERN):
     out = torch.empty(rows, h, w, cout, device="cuda")
     if prec == 0:
         ctx.call("vh_conv", L.ConvArgs(src0=xd.data_ptr(), src1=sd.data_ptr(), c0=ca, c1=cb, scale0=wa, scale1=wb, rows=rows, h=h, w=w,
-                                      up=0, taps=9, pro=1, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=out.data_ptr(),
+                                      up=0, taps=9, pro=1, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=out.data_ptr(),
                                       out_s8=None, out_s8_c=0, prec=0, kernel=0, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0, ta=0, tb=0, clip=0))
         got = out
     else:
@@ -106,7 +112,7 @@ def test_conv_res0_path_concat_up_silu_scale(ctx, prec, KERN):
                                         npix=rows * h * w, c_pad=cin_pad, out=s8.data_ptr()))
         o8 = torch.empty(rows * h * w * cout, device="cuda")
         ctx.call("vh_conv", L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin_pad, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
-                                      up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=cout, out=None,
+                                      up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=None,
                                       out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, kernel=KERN, epi=1, cvec=cd.data_ptr(), cvec_ld=cout, res=None, res_up=0,
                                       ta=0, tb=0, clip=0))
         torch.cuda.synchronize()
@@ -135,7 +141,7 @@ def test_conv_up_mpsum_clip(ctx, prec, KERN):
                                         npix=rows * h * w, c_pad=cin_pad, out=src.data_ptr()))
     out = torch.empty(rows, h, w, c, device="cuda")
     ctx.call("vh_conv", L.ConvArgs(src0=src.data_ptr(), src1=None, c0=cin_pad if prec else c, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
-                                  up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, cout=c, out=out.data_ptr(),
+                                  up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=_scratch(), scratch_floats=1 << 22, cout=c, out=out.data_ptr(),
                                   out_s8=None, out_s8_c=0, prec=prec, kernel=KERN if prec else 0, epi=2, cvec=None, cvec_ld=0, res=rd.data_ptr(), res_up=1,
                                   ta=0.7 / n, tb=0.3 / n, clip=2.0))
     torch.cuda.synchronize()

@@ -12,6 +12,7 @@ g = torch.Generator().manual_seed(0)
 x = torch.randn(rows, h, w, cin, generator=g).cuda()
 wgt = torch.randn(cout, cin, *([3, 3] if taps == 9 else [1, 1]), generator=g).cuda()
 zeros = torch.zeros(16384, device="cuda")
+scr = torch.empty(16 << 20, device="cuda")
 cin_pad = (cin + 31) // 32 * 32
 k_pad = taps * cin_pad
 M = rows * h * w
@@ -25,7 +26,7 @@ for name, prec, kern, split in (("fp32-tile128", 0, 0, 0), ("x3-tile128", 1, 0, 
                                                 gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=split))
     out = torch.empty(M, cout, device="cuda")
     a = L.ConvArgs(src0=(s8 if prec else x).data_ptr(), src1=None, c0=cin_pad if prec else cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w,
-                   up=0, taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, cout=cout,
+                   up=0, taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(), scratch_floats=scr.numel(), cout=cout,
                    out=out.data_ptr(), out_s8=None, out_s8_c=0, prec=prec, kernel=kern, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0)
     for _ in range(2):
         ctx.call("vh_conv", a)

@@ -31,7 +31,8 @@ class ConvArgs(C.Structure):
                 ("scale0", C.c_float), ("scale1", C.c_float),
                 ("rows", C.c_int), ("h", C.c_int), ("w", C.c_int), ("up", C.c_int), ("taps", C.c_int),
                 ("pro", C.c_int), ("wt", C.c_void_p), ("cin_pad", C.c_int), ("k_pad", C.c_int),
-                ("zeros", C.c_void_p), ("zeros_bytes", C.c_size_t), ("cout", C.c_int), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
+                ("zeros", C.c_void_p), ("zeros_bytes", C.c_size_t), ("cout", C.c_int),
+                ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
                 ("prec", C.c_int), ("kernel", C.c_int), ("epi", C.c_int),
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
                 ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float)]

@@ -19,6 +19,8 @@ struct ConvK {
     const float* res; int res_up;
     float ta, tb, clip;
     int M, HW, NT;
+    int ksplit; float* scratch;     // split-K: this launch covers K-tiles [ks*KT/ksplit, (ks+1)*KT/ksplit) and
+                                    // writes raw partial sums to scratch[ks][M][cout]; a reducer applies the epilogue
 };
 
 __device__ __forceinline__ float mp_silu_dev(float v) {
@@ -104,69 +106,74 @@ __device__ __forceinline__ void conv_epilogue_tiles16_lds(const ConvK& a, const 
 }
 
 // Read-out of a 32 x 36-float patch: every lane handles 4 consecutive output channels of one pixel.
+// Epilogue of 4 consecutive output channels gn..gn+3 of pixel gm (y = raw sums): shared by the LDS patch read-out
+// and by the split-K reducer.
+__device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int gn, float (&y)[4]) {
+    if (gm >= a.M || gn >= a.cout) return;
+    const bool full = gn + 3 < a.cout;
+    if (a.epi == VH_EPI_SCALE_SILU) {
+        const int img = gm / a.HW;
+        const float* cp = a.cvec + (size_t)img * a.cvec_ld + gn;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (full || gn + j < a.cout) y[j] = mp_silu_dev(y[j] * cp[j]);
+    } else if (a.epi == VH_EPI_MPSUM) {
+        size_t rrow = (size_t)gm;
+        if (a.res_up) {
+            const int Hr = a.h >> 1, Wr = a.w >> 1;
+            const int img = gm / a.HW;
+            const int rem = gm - img * a.HW;
+            const int yy = rem / a.w, xx = rem - yy * a.w;
+            rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
+        }
+        const float* rp = a.res + rrow * a.cout + gn;
+        float rv[4];
+        if (full && (a.cout & 3) == 0) {
+            const float4 t = *reinterpret_cast<const float4*>(rp);
+            rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rv[j] = (gn + j < a.cout) ? rp[j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = rv[j] * a.ta + y[j] * a.tb;
+            if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
+        }
+    }
+    if (a.out) {
+        float* op = a.out + (size_t)gm * a.cout + gn;
+        if (full && (a.cout & 3) == 0) {
+            *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (gn + j < a.cout) op[j] = y[j];
+        }
+    }
+    if (a.out_s8) {       // cout % 32 == 0 here: the 4 channels are half of one 8-channel chunk
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = bf16_rn_bits(y[j]);
+            l[j] = bf16_rn_bits(y[j] - __uint_as_float(h[j] << 16));
+        }
+        unsigned short* q = a.out_s8 + ((size_t)gm * a.out_s8_c + (size_t)(gn & ~7)) * 2 + (gn & 7);
+        *reinterpret_cast<uint2*>(q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(q + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+
 __device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane) {
     constexpr int LD = 36;
     const int cg = lane & 7, rsub = lane >> 3;
     const int gn = col0 + 4 * cg;
-    const int Hr = a.h >> 1, Wr = a.w >> 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rl = rsub + 8 * i;
         const float4 v = *reinterpret_cast<const float4*>(&patch[rl * LD + 4 * cg]);
-        const int gm = row0 + rl;
-        if (gm >= a.M || gn >= a.cout) continue;
         float y[4] = {v.x, v.y, v.z, v.w};
-        const bool full = gn + 3 < a.cout;
-        if (a.epi == VH_EPI_SCALE_SILU) {
-            const int img = gm / a.HW;
-            const float* cp = a.cvec + (size_t)img * a.cvec_ld + gn;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (full || gn + j < a.cout) y[j] = mp_silu_dev(y[j] * cp[j]);
-        } else if (a.epi == VH_EPI_MPSUM) {
-            size_t rrow = (size_t)gm;
-            if (a.res_up) {
-                const int img = gm / a.HW;
-                const int rem = gm - img * a.HW;
-                const int yy = rem / a.w, xx = rem - yy * a.w;
-                rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
-            }
-            const float* rp = a.res + rrow * a.cout + gn;
-            float rv[4];
-            if (full && (a.cout & 3) == 0) {
-                const float4 t = *reinterpret_cast<const float4*>(rp);
-                rv[0] = t.x; rv[1] = t.y; rv[2] = t.z; rv[3] = t.w;
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) rv[j] = (gn + j < a.cout) ? rp[j] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                y[j] = rv[j] * a.ta + y[j] * a.tb;
-                if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
-            }
-        }
-        if (a.out) {
-            float* op = a.out + (size_t)gm * a.cout + gn;
-            if (full && (a.cout & 3) == 0) {
-                *reinterpret_cast<float4*>(op) = make_float4(y[0], y[1], y[2], y[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (gn + j < a.cout) op[j] = y[j];
-            }
-        }
-        if (a.out_s8) {       // cout % 32 == 0 here: the 4 channels are half of one 8-channel chunk
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                h[j] = bf16_rn_bits(y[j]);
-                l[j] = bf16_rn_bits(y[j] - __uint_as_float(h[j] << 16));
-            }
-            unsigned short* q = a.out_s8 + ((size_t)gm * a.out_s8_c + (size_t)(gn & ~7)) * 2 + (gn & 7);
-            *reinterpret_cast<uint2*>(q) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-            *reinterpret_cast<uint2*>(q + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
-        }
+        conv_epilogue_vec4(a, row0 + rl, gn, y);
     }
 }
 

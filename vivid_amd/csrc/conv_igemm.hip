@@ -266,6 +266,8 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.out = a.out; k.out_s8 = static_cast<unsigned short*>(a.out_s8); k.out_s8_c = a.out_s8_c; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;
     k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
+    k.ksplit = 1; k.scratch = nullptr;
+    VH_REQUIRE(!a.scratch || vh_aligned16(a.scratch), "vh_conv: scratch must be 16-byte aligned");
     const int taps = a.taps, prec = a.prec;
     const unsigned grid = (unsigned)(MT * NT);
     // algorithmic work: 2*M*cout*cin*taps FLOPs; bytes = input + weights + output (+ residual), each once

@@ -14,6 +14,7 @@
 // K runs tap-major in 32-channel tiles; per tap each thread derives its 4 pixel pointers (zero page outside
 // the image).  Two LDS stages; the loads of tile t+1 are in flight during the MFMAs of tile t.
 #include "conv_common.h"
+#include <algorithm>
 #include <cstdlib>
 
 namespace {
@@ -58,7 +59,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
 
     const int t = threadIdx.x;
     const int w = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
-    const unsigned tile = xcd_tile_id();
+    const unsigned tile0 = xcd_tile_id();
+    const unsigned ntiles_mn = gridDim.x / a.ksplit;
+    const int ks = tile0 / ntiles_mn;                      // K slice of this workgroup (split-K; 0 when ksplit == 1)
+    const unsigned tile = tile0 - ks * ntiles_mn;
     const int nt = tile % a.NT, mt = tile / a.NT;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -204,10 +208,14 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     };
 
     // ---- main loop: DMA of tile t+1 in flight during the MFMAs of tile t; one barrier per tile ------------
-    const int KT = a.k_pad / BK;
-    int tap = 0, cc = 0;
-    setup_tap(0);
-    issue(0, 0);
+    const int KTall = a.k_pad / BK;
+    const int kt0 = (int)((long long)KTall * ks / a.ksplit), KT = (int)((long long)KTall * (ks + 1) / a.ksplit) - kt0;
+    int tap = (kt0 * BK) / a.cin_pad, cc = kt0 * BK - tap * a.cin_pad;
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+        if (!bzero[j]) pb[j] += (size_t)kt0 * 8;
+    setup_tap(tap);
+    issue(0, cc);
     wait_dma();
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
@@ -228,15 +236,43 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
 
     // the loop's last barrier has retired every read of the stages: reuse sA as 8 per-wave transpose patches
     float* patch = reinterpret_cast<float*>(&sA[0][0]) + w * (32 * 36);
+    ConvK e = a;
+    if (a.ksplit > 1) {                                    // raw partial sums; vh_conv's reducer applies the epilogue
+        e.epi = VH_EPI_STORE;
+        e.out = a.scratch + (size_t)ks * a.M * a.cout;
+        e.out_s8 = nullptr;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
             if constexpr (M16)
-                conv_epilogue_tiles16_lds(a, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
+                conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
                                           acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
             else
-                conv_epilogue_tile_lds(a, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
+                conv_epilogue_tile_lds(e, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
+}
+
+// split-K reducer: sums the ksplit partial-sum slabs and applies the epilogue; one thread per 4 output channels
+__global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c4 = (a.cout + 3) >> 2;
+    const int gm = (int)(i / c4), gn = (int)(i - (long long)gm * c4) * 4;
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t slab = (size_t)a.M * a.cout;
+    const float* p = a.scratch + (size_t)gm * a.cout + gn;
+    for (int s = 0; s < a.ksplit; ++s, p += slab) {
+        if ((a.cout & 3) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(p);
+            y[0] += v.x; y[1] += v.y; y[2] += v.z; y[3] += v.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (gn + j < a.cout) y[j] += p[j];
+        }
+    }
+    conv_epilogue_vec4(a, gm, gn, y);
 }
 
 }  // namespace
@@ -252,7 +288,17 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
     k.NT = (int)NT;
-    const unsigned grid = (unsigned)(MT * NT);
+    // split-K for grids that leave most of the chip idle (low-resolution levels / small batches): slice the K loop over
+    // `ksplit` workgroups per tile, partial sums through a scratch slab, epilogue in a small reducer launch
+    const int KTall = a.k_pad / BK;
+    int ksplit = 1;
+    if (a.scratch && MT * NT < 192 && KTall >= 16) {
+        ksplit = (int)std::min<long long>(std::min<long long>(8, (383 + MT * NT) / (MT * NT)), KTall / 8);
+        while (ksplit > 1 && (size_t)ksplit * (size_t)M * a.cout > a.scratch_floats) --ksplit;
+    }
+    k.ksplit = ksplit;
+    k.scratch = a.scratch;
+    const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
     static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
     const int cfg = tall ? 2 : wide ? 1 : 0;
@@ -269,6 +315,10 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         else { if (use16) VH_LAUNCH_CFG(1, true); else VH_LAUNCH_CFG(1, false); }
 #undef VH_LAUNCH_CFG
 #undef VH_LAUNCH
+        if (k.ksplit > 1) {
+            const long long total4 = (long long)k.M * ((k.cout + 3) / 4);
+            hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, k, total4);
+        }
         return vh_check_launch("conv_x3_glds");
     });
 }

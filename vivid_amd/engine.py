@@ -154,6 +154,7 @@ class Engine:
         (the reference repeats this on every forward, training/models.py:115-120)."""
         self._ensure_ctx(device)
         self.zeros = torch.zeros(16384, dtype=torch.float32, device=device)     # 64 KiB zero page for vh_conv
+        self.scratch = torch.empty(16 << 20, dtype=torch.float32, device=device) if self.glds else None   # split-K partial sums (64 MiB)
         self.W.clear()
         self.embW.clear()
         self.programs.clear()
@@ -283,6 +284,8 @@ class Engine:
                        scale0=sc0, scale1=sc1, rows=rows, h=h, w=w, up=up, taps=W.taps, pro=pro,
                        wt=W.wt.data_ptr(), cin_pad=W.cin_pad, k_pad=W.k_pad,
                        zeros=self.zeros.data_ptr() if getattr(self, "zeros", None) is not None else None, zeros_bytes=65536, cout=W.cout,
+                       scratch=self.scratch.data_ptr() if getattr(self, "scratch", None) is not None else None,
+                       scratch_floats=self.scratch.numel() if getattr(self, "scratch", None) is not None else 0,
                        out=out.ptr if out is not None else None, out_s8=out_s8.ptr if out_s8 is not None else None,
                        out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, kernel=1 if (prec and self.glds) else 0, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
