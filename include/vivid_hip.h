@@ -59,6 +59,7 @@ int vh_profile_read_list(vh_ctx* ctx, int max_n, int* tags, double* ms, double* 
 
 int vh_plan_begin(vh_ctx* ctx);
 int vh_plan_end(vh_ctx* ctx, vh_plan** out);
+int vh_plan_capture_graph(vh_ctx* ctx, vh_plan* plan);   /* optional: replay through one hipGraphLaunch (launch-bound shapes) */
 int vh_plan_run(vh_ctx* ctx, const vh_plan* plan);
 int vh_plan_num_ops(const vh_plan* plan);
 int vh_plan_destroy(vh_plan* plan);

@@ -130,7 +130,7 @@ OPS = {
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
 CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
-           "vh_plan_begin", "vh_plan_end", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
+           "vh_plan_begin", "vh_plan_end", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
 _lib = None
 
@@ -156,6 +156,7 @@ def lib():
     L.vh_plan_begin.argtypes = [C.c_void_p]
     L.vh_plan_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.vh_plan_run.argtypes = [C.c_void_p, C.c_void_p]
+    L.vh_plan_capture_graph.argtypes = [C.c_void_p, C.c_void_p]
     L.vh_plan_num_ops.argtypes = [C.c_void_p]
     L.vh_plan_destroy.argtypes = [C.c_void_p]
     for name, st in OPS.items():
@@ -237,6 +238,9 @@ class Plan:
     @property
     def num_ops(self) -> int:
         return self.ctx._L.vh_plan_num_ops(self.handle)
+
+    def capture_graph(self):
+        check(self.ctx._L.vh_plan_capture_graph(self.ctx.handle, self.handle), "vh_plan_capture_graph")
 
     def run(self):
         check(self.ctx._L.vh_plan_run(self.ctx.handle, self.handle), "vh_plan_run")

@@ -119,9 +119,43 @@ extern "C" int vh_plan_end(vh_ctx* ctx, vh_plan** out) {
     return VH_OK;
 }
 
+// Capture the plan's launches into a hipGraph (on a private capture stream: the legacy default stream cannot be
+// captured) and instantiate it; vh_plan_run then replays the whole evaluation with one hipGraphLaunch.
+extern "C" int vh_plan_capture_graph(vh_ctx* ctx, vh_plan* plan) {
+    if (!ctx || !plan) return vh_fail(VH_EINVAL, "vh_plan_capture_graph: null argument");
+    if (ctx->recording) return vh_fail(VH_ESTATE, "vh_plan_capture_graph: context is recording");
+    if (plan->exec) return VH_OK;
+    hipStream_t cs = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_plan_capture_graph: %s", hipGetErrorString(e));
+    e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipStreamDestroy(cs); return vh_fail(VH_EHIP, "vh_plan_capture_graph: begin: %s", hipGetErrorString(e)); }
+    int rc = VH_OK;
+    for (const auto& op : plan->ops) {
+        rc = op.launch(cs);
+        if (rc != VH_OK) break;
+    }
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(cs, &g);
+    (void)hipStreamDestroy(cs);
+    if (rc != VH_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) return vh_fail(VH_EHIP, "vh_plan_capture_graph: end: %s", hipGetErrorString(e));
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); return vh_fail(VH_EHIP, "vh_plan_capture_graph: instantiate: %s", hipGetErrorString(e)); }
+    plan->graph = g;
+    plan->exec = ex;
+    return VH_OK;
+}
+
 extern "C" int vh_plan_run(vh_ctx* ctx, const vh_plan* plan) {
     if (!ctx || !plan) return vh_fail(VH_EINVAL, "vh_plan_run: null argument");
     if (ctx->recording) return vh_fail(VH_ESTATE, "vh_plan_run: context is recording");
+    if (plan->exec && !ctx->profiling) {
+        const hipError_t e = hipGraphLaunch(plan->exec, ctx->stream);
+        if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_plan_run: hipGraphLaunch: %s", hipGetErrorString(e));
+        return VH_OK;
+    }
     for (const auto& op : plan->ops) {
         const int rc = vh_run_op(ctx, op);
         if (rc != VH_OK) return rc;
@@ -132,6 +166,10 @@ extern "C" int vh_plan_run(vh_ctx* ctx, const vh_plan* plan) {
 extern "C" int vh_plan_num_ops(const vh_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
 
 extern "C" int vh_plan_destroy(vh_plan* plan) {
+    if (plan) {
+        if (plan->exec) (void)hipGraphExecDestroy(plan->exec);
+        if (plan->graph) (void)hipGraphDestroy(plan->graph);
+    }
     delete plan;
     return VH_OK;
 }

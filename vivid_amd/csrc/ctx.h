@@ -18,6 +18,8 @@ struct vh_op {
 
 struct vh_plan {
     std::vector<vh_op> ops;
+    hipGraph_t graph = nullptr;          // the same launches captured into a hipGraph (vh_plan_capture_graph)
+    hipGraphExec_t exec = nullptr;
 };
 
 struct vh_prof_rec {
