@@ -210,12 +210,13 @@ def test_qkv_split_and_attention(ctx, x3, b, heads, s, kl, d, nz):
     assert rel_l2(out.cpu(), ref.permute(0, 2, 1)) < (1e-4 if x3 else 2e-5)
 
 
-@pytest.mark.parametrize("s", [64, 256])
-def test_attention_softmax_rescale_branch(ctx, s):
+@pytest.mark.parametrize("s,kl", [(64, 448), (256, 448), (256, 512), (200, 1000)])
+def test_attention_softmax_rescale_branch(ctx, s, kl):
     """Force the running-max update late in the key sequence: one key matches one query far better
     than everything before it (cdna guide rule 26: a rare data-dependent branch needs its own test)."""
     from vivid_amd import _lib as L
-    b, heads, kl, d = 1, 1, 512, 64          # s=256 runs the software-pipelined x3 kernel, s=64 the plain one
+    # s=64 runs the plain x3 kernel, s>128 the software-pipelined one; (200,1000) has ragged query and key tails
+    b, heads, d = 1, 1, 64
     g = torch.Generator().manual_seed(99)
     q = torch.randn(b, heads, s, d, generator=g) * 0.05
     k = torch.randn(b, heads, kl, d, generator=g) * 0.05
@@ -225,7 +226,7 @@ def test_attention_softmax_rescale_branch(ctx, s):
     k[0, 0, 130] = 1.0 * torch.ones(d)
     ref = torch.nn.functional.scaled_dot_product_attention(q, k, v)
     for x3 in (0, 1):
-        klp = kl
+        klp = (kl + 63) // 64 * 64
         Qd = (q * (LOG2E / math.sqrt(d))).contiguous().cuda()
         kd, vd = k.cuda(), v.cuda()
         out = torch.empty(b, s, heads * d, device="cuda")
@@ -236,6 +237,7 @@ def test_attention_softmax_rescale_branch(ctx, s):
             # build the x3 operand formats through the split kernel from an un-normalised source is not possible
             # (it normalises), so lay them out here: K as S8, V transposed with the bit-2/3 key permutation.
             def split(t):
+                t = torch.nn.functional.pad(t, (0, 0, 0, klp - kl))
                 hi = t.to(torch.bfloat16).to(torch.float32)
                 lo = (t - hi).to(torch.bfloat16)
                 return t.to(torch.bfloat16), lo

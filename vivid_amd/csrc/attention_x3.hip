@@ -48,6 +48,22 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
 }
 
+// same, two elements at a time (v_pk_add_f32), also accumulating the sum of the 8 values into acc
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8_sum(const float* v, bf16x8& hi, bf16x8& lo, f32x2& acc) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 x = {v[2 * j], v[2 * j + 1]};
+        acc += x;
+        hi[2 * j] = (__bf16)x.x;
+        hi[2 * j + 1] = (__bf16)x.y;
+        const f32x2 hf = {(float)hi[2 * j], (float)hi[2 * j + 1]};
+        const f32x2 d = x - hf;
+        lo[2 * j] = (__bf16)d.x;
+        lo[2 * j + 1] = (__bf16)d.y;
+    }
+}
+
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
     constexpr int NT = NW * 64;
@@ -318,7 +334,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[dt][r] = 0.f;
-    float mrow = 0.f;
     float lsum = a.n_zero;
 
     constexpr int KPT = K_UNITS / NT, VPT = V_UNITS / NT;
@@ -385,16 +400,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     const bool ragged = (a.kl % KT) != 0;
     auto is_tail = [&](int tile) { return ragged && tile == ntiles - 1; };
 
-    // initial accumulator of a sub-tile's logits: -m, or -inf for keys past the end of a ragged last tile
-    auto init_s = [&](f32x16& sacc, int k0, int ks, bool tail) {
-        if (tail) {
-            const int kbase = k0 + ks * 32 + 4 * hh;
+    // The running max enters the logits as the MFMA chain's initial accumulator: a register tile holding -m in
+    // every element, kept across sub-tiles (16 VGPRs instead of 16 v_mov per sub-tile).
+    f32x16 negm;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = (kbase + (r & 3) + 8 * (r >> 2) < a.kl) ? -mrow : -INFINITY;
-        } else {
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    // keys past the end of a ragged last tile get -inf logits (exp2 -> 0)
+    auto mask_tail = [&](f32x16& sacc, int k0, int ks) {
+        const int kbase = k0 + ks * 32 + 4 * hh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[r] = -mrow;
-        }
+        for (int r = 0; r < 16; ++r)
+            if (kbase + (r & 3) + 8 * (r >> 2) >= a.kl) sacc[r] = -INFINITY;
     };
     auto qk = [&](f32x16& sacc, int slot, int ks) {
         const int key = ks * 32 + lr;
@@ -403,54 +419,46 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
             const int uh = (sl * 2 + hh) * 2, ul = uh + 1;
             const bf16x8 kh = *reinterpret_cast<const bf16x8*>(&sK[slot][uh * KT + (key ^ (uh & 7))]);
             const bf16x8 kl_ = *reinterpret_cast<const bf16x8*>(&sK[slot][ul * KT + (key ^ (ul & 7))]);
-            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl_, qh[sl], sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl_, qh[sl], sl == 0 ? negm : sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[sl], sacc, 0, 0, 0);
             sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[sl], sacc, 0, 0, 0);
         }
     };
 
     f32x16 scur, snext;
-    bool first = !(a.n_zero > 0.f);
 
     // one pipeline step: finish sub-tile (vslot, vks) whose logits are in scur; start the next one if any
-    auto step = [&](int vslot, int vks, bool has_next, int nslot, int nks, int nk0, bool ntail) {
+    // (the sub-tile after the last one is computed too, from whatever the idle K slot holds, and never used: a
+    // `has_next` branch around qk() would cut region B in two and its MFMAs would issue without the VALU work)
+    auto step = [&](int vslot, int vks, int nslot, int nks, int nk0, bool ntail) {
         // region A: row max of the current logits (scur = s - m), rare raise of the running max
         float mx = scur[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (first) {                                        // no max yet: adopt this sub-tile's (O and l are still 0)
-            first = false;
-            mrow = mx;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) scur[r] -= mx;
-        } else if (__any(mx > RESCALE_THR)) {
+        if (__any(mx > RESCALE_THR)) {
             const float dm = fmaxf(mx, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-dm);
             lsum *= alpha;
-            mrow += dm;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) scur[r] -= dm;
+            for (int r = 0; r < 16; ++r) { scur[r] -= dm; negm[r] -= dm; }
 #pragma unroll
             for (int dt = 0; dt < D / 32; ++dt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
         }
-        if (has_next) init_s(snext, nk0, nks, ntail);
         // region B: next sub-tile's QK^T on the matrix pipe, this sub-tile's exp / sum / bf16 split on the VALU
-        if (has_next) qk(snext, nslot, nks);
-        float rs = 0.f;
+        qk(snext, nslot, nks);
+        f32x2 rs2 = {0.f, 0.f};
         bf16x8 ph[2], pl[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pv[j] = __builtin_amdgcn_exp2f(scur[8 * s2 + j]);
-                rs += pv[j];
-            }
-            split8(pv, ph[s2], pl[s2]);
+            for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(scur[8 * s2 + j]);
+            split8_sum(pv, ph[s2], pl[s2], rs2);
         }
+        float rs = rs2.x + rs2.y;
         rs += __shfl_xor(rs, 32);
         lsum += rs;
         // O^T += V^T P^T
@@ -467,7 +475,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
                 oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph[s2], oacc[dt], 0, 0, 0);
             }
         }
-        if (has_next) scur = snext;
+        if (ntail) mask_tail(snext, nk0, nks);               // (after the matrix work: keeps region B one basic block)
+        scur = snext;
     };
 
     // prologue: K[0], V[0], K[1] in LDS; logits of sub-tile 0
@@ -475,8 +484,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     storeK(0, 0, is_tail(0)); storeV(0, 0, is_tail(0));
     if (ntiles > 1) { loadK(); storeK(1, KT, is_tail(1)); }
     __syncthreads();
-    init_s(scur, 0, 0, is_tail(0));
     qk(scur, 0, 0);
+    if (is_tail(0)) mask_tail(scur, 0, 0);
+    if (!(a.n_zero > 0.f)) {                                // no max yet: adopt sub-tile 0's (O and l are still 0)
+        float mx = scur[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { scur[r] -= mx; negm[r] = -mx; }
+    }
 
     int ks0 = 0, ks1 = 1, ks2 = 2;                          // K slots of tiles t, t+1, t+2
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -484,8 +501,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
         if (more2) loadK();
         if (more1) loadV();
-        step(tile & 1, 0, true, ks0, 1, k0, is_tail(tile));
-        step(tile & 1, 1, more1, ks1, 0, k0 + KT, is_tail(tile + 1));
+        step(tile & 1, 0, ks0, 1, k0, is_tail(tile));
+        step(tile & 1, 1, ks1, 0, k0 + KT, is_tail(tile + 1));
         if (more2) storeK(ks2, k0 + 2 * KT, is_tail(tile + 2));
         if (more1) storeV((tile + 1) & 1, k0 + KT, is_tail(tile + 1));
         __syncthreads();
