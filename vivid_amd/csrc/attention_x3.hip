@@ -48,22 +48,6 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
 }
 
-// same, two elements at a time (v_pk_add_f32), also accumulating the sum of the 8 values into acc
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void split8_sum(const float* v, bf16x8& hi, bf16x8& lo, f32x2& acc) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x2 x = {v[2 * j], v[2 * j + 1]};
-        acc += x;
-        hi[2 * j] = (__bf16)x.x;
-        hi[2 * j + 1] = (__bf16)x.y;
-        const f32x2 hf = {(float)hi[2 * j], (float)hi[2 * j + 1]};
-        const f32x2 d = x - hf;
-        lo[2 * j] = (__bf16)d.x;
-        lo[2 * j + 1] = (__bf16)d.y;
-    }
-}
-
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
     constexpr int NT = NW * 64;
@@ -449,16 +433,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         }
         // region B: next sub-tile's QK^T on the matrix pipe, this sub-tile's exp / sum / bf16 split on the VALU
         qk(snext, nslot, nks);
-        f32x2 rs2 = {0.f, 0.f};
+        float rs = 0.f;
         bf16x8 ph[2], pl[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(scur[8 * s2 + j]);
-            split8_sum(pv, ph[s2], pl[s2], rs2);
+            for (int j = 0; j < 8; ++j) {
+                pv[j] = __builtin_amdgcn_exp2f(scur[8 * s2 + j]);
+                rs += pv[j];
+            }
+            split8(pv, ph[s2], pl[s2]);
         }
-        float rs = rs2.x + rs2.y;
         rs += __shfl_xor(rs, 32);
         lsum += rs;
         // O^T += V^T P^T
