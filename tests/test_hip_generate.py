@@ -97,5 +97,5 @@ def test_sr_cascade_runs():
 
 def test_pickle_paths_are_refused():
     from vivid_amd.generate import generate_images_nvs
-    with pytest.raises(NotImplementedError, match="out of scope"):
+    with pytest.raises(NotImplementedError, match="needs the network"):
         generate_images_nvs("https://example.invalid/vivid-base.pkl", data=[])

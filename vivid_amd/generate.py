@@ -4,9 +4,9 @@ Mirrors ``generate_images_nvs`` of the reference (``generate_images.py:139-343``
 SURVEY.md 8(f): the same arguments where they make sense here, the same per-batch flow and the same result
 records (``images, src, tgt, labels, noise, seeds, batch_idx, num_batches, indices``).  What is different, and why:
 
-* networks are modules, not pickle paths/URLs: the reference unpickles ``network-snapshot-*.pkl`` files fetched
-  from a CDN with source code embedded by ``torch_utils.persistence`` (``generate_images.py:164-174``) — out of
-  scope; a string raises with that explanation;
+* networks are modules or paths of local ``network-snapshot-*.pkl`` files; a path is decoded by
+  ``vivid_amd.snapshot`` — a restricted unpickler that never executes the source text those files embed
+  (the reference ``pickle.load``s them, ``generate_images.py:164-174``).  URLs raise: there is no network here;
 * data comes from any iterable of collated batches instead of ``CustomLitDataset``/``DataLoader`` over litdata
   chunks (``:211-226``, out of scope SURVEY 2.1 #11).  A batch is a dict with ``src_image``, ``tgt_image``
   (uint8-range ``[rows,3,H,W]``) and ``geometry`` (``[rows,20]``), rows interleaved ``[s1,s2,s1,s2,...]`` in
@@ -76,9 +76,15 @@ def generate_images_nvs(
     rng_device=None,                                # device of the per-seed generators (default: `device`, as the reference)
     **sampler_kwargs,
 ):
-    if isinstance(net, str) or isinstance(gnet, str) or isinstance(sr_model, str):
-        raise NotImplementedError("loading network pickles/URLs is out of scope (the reference's snapshots embed and execute "
-                                  "pickled source, generate_images.py:164-174); pass constructed networks")
+    def resolve(m, name):                                                                  # :164-196, without pickle.load
+        if not isinstance(m, str):
+            return m
+        if "://" in m:
+            raise NotImplementedError(f"{name}: fetching {m!r} needs the network (the reference's dnnlib.util.open_url); "
+                                      "download the snapshot and pass its path")
+        from .snapshot import load_network_pkl
+        return load_network_pkl(m, dual_source=True if dual_source is None else dual_source).to(device)
+    net, gnet, sr_model = resolve(net, "net"), resolve(gnet, "gnet"), resolve(sr_model, "sr_model")
     if data is None:
         raise ValueError("generate_images_nvs needs `data`: an iterable of collated batches (the litdata loader is out of scope)")
     device = torch.device(device)
