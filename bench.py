@@ -238,6 +238,17 @@ def main():
                                "note": ("achieved = algorithmic fp32 FLOPs/s; every fp32 product is 3 bf16 MFMA products (hi*hi+hi*lo+lo*hi, "
                                         "fp32 accumulate), so peak = 2500 TF/s dense bf16 MFMA / 3; executed MFMA rate = 3 x achieved"
                                         if x3 else "fp32 operands on v_mfma_f32_32x32x2_f32; peak = fp32 matrix peak (no xf32 on gfx950)")}
+            tr = traffic.get(dom)
+            if tr is not None:                              # measured HBM stream of the same kernel: bytes per launch / launch time
+                out["roofline"]["hbm_gbs"] = tr / (vd["ms"] / vd["launches"] / 1e3) / 1e9
+                out["roofline"]["hbm_frac"] = out["roofline"]["hbm_gbs"] / PEAK_HBM_GBS
+            # north_star also asks for the attention kernels' MFMA utilisation: same definition, second family
+            if "attention" in kern and dom != "attention":
+                ka, va = kern["attention"], fam["attention"]
+                pk = PEAK_BF16_MFMA_TFLOPS / 3.0 if args.precision == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
+                out["roofline_attention"] = {"bound": "mfma", "achieved": ka["tflops"], "peak": pk, "unit": "TFLOP/s",
+                                             "frac": ka["tflops"] / pk, "avg_launch_ms": va["ms"] / va["launches"],
+                                             "traffic": traffic.get("attention"), "share_of_step": ka["ms_per_step"] / out["ms_per_step"]}
             out["kernels"] = kern
             tot_fl = sum(v["flops"] for v in fam.values())
             out["whole_step_tflops"] = tot_fl / elapsed / 1e12
