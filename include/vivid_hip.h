@@ -189,6 +189,10 @@ typedef struct {
     float n_zero_keys;
     float* out;
     int out_s8;               /* vh_attention_x3 only: write `out` in the S8 (bf16 hi/lo) layout for a bf16x3 attn_proj */
+    float logit_bound;        /* vh_attention_x3 only: caller's guarantee |q.k| <= logit_bound for every pair (q as passed,
+                               * i.e. in log2 units); 0 = none.  vh_qkv_split* output satisfies sqrt(D)*log2(e): the
+                               * head vectors are RMS-normalised.  With 0 < bound <= 64 no running maximum is kept
+                               * (exp2 of the raw logits cannot overflow fp32), the result is the same softmax. */
 } vh_attention_args;
 int vh_attention(vh_ctx* ctx, const vh_attention_args* a);
 

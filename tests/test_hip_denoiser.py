@@ -116,3 +116,26 @@ def test_cpu_input_fails_loudly():
     inp = make_inputs(case)
     with pytest.raises(RuntimeError, match="MI355X"):
         net(inp["src"], inp["img"], torch.ones(inp["src"].shape[0]), inp["geometry"])
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_non_power_of_two_resolution_vs_oracle(precision):
+    """24x24 images (levels 24/12/6/3, attention at 12x12 and 6x6: S = 144 and 36, neither a multiple of the 64-key
+    tile; no conv tile, image row or pooling window lines up with a power of two).  The reference accepts any
+    resolution divisible by 8 (training/models.py:330-336); checked against the oracle on the same inputs."""
+    from oracle import vivid_ref
+    from vivid_amd.arch import NetConfig
+    import vivid_amd
+    cfg = NetConfig(img_resolution=24, model_channels=64, attn_resolutions=[12, 6])
+    case = dict(cfg=cfg, seed=41, B=3)
+    inp = make_inputs(case)
+    sd = vivid_amd.synth_state_dict(cfg, seed=41)
+    net = _net(cfg, 41, True, precision)
+    for sigma in (7.0, 0.3):
+        sig = torch.full((inp["src"].shape[0],), sigma)
+        x = x_for(inp, sigma)
+        want, want_lv = vivid_ref.nvprecond_forward(sd, cfg.to_dict(), inp["src"], x, sig, inp["geometry"], None, return_logvar=True)
+        got, got_lv = net(inp["src"].cuda(), x.cuda(), sig.cuda(), inp["geometry"].cuda(), None, return_logvar=True)
+        assert got.shape == want.shape == (3, 3, 24, 24)
+        assert rel_l2(got.cpu(), want) < TOL_D[precision], (precision, sigma)
+        assert rel_l2(got_lv.cpu(), want_lv) < 2e-5

@@ -21,7 +21,7 @@ for x3 in (0, 1):
     ctx.call(sp, L.QkvSplitArgs(inp=qkv.data_ptr(), rows=b, s=S, heads=heads, d=D, nj=3, rows_per_b=1, koff=0, kl=KL, qscale=1.4426950408889634 / math.sqrt(D), q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr()))
     if KL > S:
         ctx.call(sp, L.QkvSplitArgs(inp=kv.data_ptr(), rows=b, s=KL - S, heads=heads, d=D, nj=2, rows_per_b=1, koff=S, kl=KL, qscale=1.0, q=None, k=K.data_ptr(), v=V.data_ptr()))
-    a = L.AttentionArgs(q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), b=b, heads=heads, s=S, kl=KL, d=D, n_zero_keys=0.0, out=out.data_ptr(), out_s8=0)
+    a = L.AttentionArgs(q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), b=b, heads=heads, s=S, kl=KL, d=D, n_zero_keys=0.0, out=out.data_ptr(), out_s8=0, logit_bound=(1.4426950408889634 * math.sqrt(D) * 1.001 if (x3 and os.environ.get('BOUND', '1') != '0') else 0.0))
     for _ in range(2): ctx.call(at, a)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

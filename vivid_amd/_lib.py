@@ -58,7 +58,7 @@ class QkvSplitArgs(C.Structure):
 class AttentionArgs(C.Structure):
     _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("b", C.c_int),
                 ("heads", C.c_int), ("s", C.c_int), ("kl", C.c_int), ("d", C.c_int),
-                ("n_zero_keys", C.c_float), ("out", C.c_void_p), ("out_s8", C.c_int)]
+                ("n_zero_keys", C.c_float), ("out", C.c_void_p), ("out_s8", C.c_int), ("logit_bound", C.c_float)]
 
 
 class EmbedArgs(C.Structure):

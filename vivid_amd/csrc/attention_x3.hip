@@ -283,7 +283,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
 // K lives in a 3-slot LDS ring (tile t+1's first sub-tile is needed while tile t is still being consumed),
 // V in 2 slots; K[t+2] and V[t+1] are fetched to registers during tile t and stored before its closing barrier.
 // Key masking of a ragged last tile is done through the MFMA's initial accumulator (-inf + x = -inf).
-template <int D>
+// NOMAX: the caller bounds the logits (vh_attention_args.logit_bound), so exp2 is taken of the raw logits: no row
+// maximum, no rescale branch, a zero initial accumulator.  The phantom zero-logit keys then weigh exactly 1 each.
+template <int D, bool NOMAX = false>
 __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     constexpr int NT = 512;
     constexpr int KU = D / 4;
@@ -416,11 +418,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     // `has_next` branch around qk() would cut region B in two and its MFMAs would issue without the VALU work)
     auto step = [&](int vslot, int vks, int nslot, int nks, int nk0, bool ntail) {
         // region A: row max of the current logits (scur = s - m), rare raise of the running max
-        float mx = scur[0];
+        float mx = 0.f;
+        if constexpr (!NOMAX) {
+            mx = scur[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__any(mx > RESCALE_THR)) {
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+        }
+        if (!NOMAX && __any(mx > RESCALE_THR)) {
             const float dm = fmaxf(mx, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-dm);
             lsum *= alpha;
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     __syncthreads();
     qk(scur, 0, 0);
     if (is_tail(0)) mask_tail(scur, 0, 0);
-    if (!(a.n_zero > 0.f)) {                                // no max yet: adopt sub-tile 0's (O and l are still 0)
+    if (!NOMAX && !(a.n_zero > 0.f)) {                      // no max yet: adopt sub-tile 0's (O and l are still 0)
         float mx = scur[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, scur[r]);
@@ -651,12 +656,16 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     const int nw = a.s > 128 ? 8 : 4;
     static const bool use_pipe = !(getenv("VIVID_ATTN_PIPE") && atoi(getenv("VIVID_ATTN_PIPE")) == 0);
     const bool pipe = use_pipe && nw == 8 && a.kl > KT && a.d == 64;   // (the D=32 instantiation spills its accumulators)
+    VH_REQUIRE(a.logit_bound >= 0.f, "vh_attention_x3: negative logit_bound");
+    static const bool nomax_on = !(getenv("VIVID_ATTN_NOMAX") && atoi(getenv("VIVID_ATTN_NOMAX")) == 0);
+    const bool nomax = nomax_on && a.logit_bound > 0.f && a.logit_bound <= 64.f;
     const dim3 grid((a.s + nw * 32 - 1) / (nw * 32), a.b * a.heads);
     const double bhd = (double)a.b * a.heads;
     const double flops = 4.0 * bhd * a.s * a.kl * a.d;
     const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);
-    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, grid](hipStream_t s) -> int {
-        if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
+    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, nomax, grid](hipStream_t s) -> int {
+        if (pipe && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64, true>), grid, dim3(512), 0, s, k);
+        else if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
         else if (d == 64 && nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 8>), grid, dim3(512), 0, s, k);
         else if (d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 4>), grid, dim3(256), 0, s, k);
         else if (nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<32, 8>), grid, dim3(512), 0, s, k);

@@ -443,7 +443,8 @@ class Engine:
                 self._free(kv)
             att = self._alloc(rows, R, R, C)
             self._call(attn_op, L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
-                                                n_zero_keys=nz, out=att.ptr, out_s8=1 if ax3 else 0),
+                                                n_zero_keys=nz, out=att.ptr, out_s8=1 if ax3 else 0,
+                                                logit_bound=LOG2E * math.sqrt(D) * 1.001),   # q, k are RMS-normalised head vectors
                        f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz} x3={int(ax3)}")
             self._free(q); self._free(k); self._free(v)
             ta2, tb2 = self._mp_sum_coeffs(cfg.attn_balance)
