@@ -546,10 +546,13 @@ __device__ __forceinline__ int perm16(int key) {      // swap bits 2 and 3
     return (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
 }
 
-template <int D>
+// All global traffic is 12/8-byte-per-lane contiguous loads (a lane's q,k,v or k,v of one channel) and 16-byte stores:
+// K rows (S8) and V^T rows are assembled in LDS and written as whole units, Q is one 256-byte row per wave store.
+template <int D, int NJ>
 __global__ __launch_bounds__(256) void qkv_split_x3_k(const SplitXK a) {
     constexpr int PG = 256 / D;                  // pixels handled per pass
-    __shared__ unsigned short sv[D * 2 * 64];    // [d][hl][64 local positions]
+    __shared__ unsigned short sv[D * 2 * 64];    // V^T: [d][hl][64 local positions]
+    __shared__ unsigned short sk[64 * D * 2];    // K:   [pixel][D/8][hi8|lo8]
     const int t = threadIdx.x;
     const int d = t % D, g = t / D;
     const int ntile = (a.s + 63) / 64;
@@ -563,18 +566,31 @@ __global__ __launch_bounds__(256) void qkv_split_x3_k(const SplitXK a) {
     // fast path: the tile maps onto whole 16-key groups of this row's key range (V^T transposed through LDS)
     const bool fast = (a.s % 16 == 0) && (((kbase + s0) & 15) == 0);
     const float rsd = rsqrtf((float)D);
-    for (int pp = g; pp < 64; pp += PG) {
+    // all of this thread's loads first (one dwordx3 / dwordx2 per lane and pixel, 64 / PG of them in flight: with one
+    // load per loop iteration the kernel sat at 2.8 TB/s, latency-bound)
+    constexpr int NIT = 64 / PG;
+    float vall[NIT][NJ];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int s = min(s0 + g + it * PG, a.s - 1);
+        const float* in = a.in + (((size_t)row * a.s + s) * a.heads * D + (size_t)head * D + d) * NJ;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) vall[it][j] = in[j];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int pp = g + it * PG;
         const int s = s0 + pp;
         const bool ok = s < a.s;
-        const float* in = a.in + (((size_t)row * a.s + (ok ? s : 0)) * a.heads * D + (size_t)head * D + d) * a.nj;
-        for (int j = 0; j < a.nj; ++j) {
-            const float v = ok ? in[j] : 0.f;
-            float ss = v * v;
+        const float* v = vall[it];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float ss = ok ? v[j] * v[j] : 0.f;
 #pragma unroll
             for (int o = D / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
-            const float y = v / (1e-4f + sqrtf(ss) * rsd);
-            const bool is_q = (a.nj == 3 && j == 0);
-            const bool is_k = (a.nj == 3) ? (j == 1) : (j == 0);
+            const float y = (ok ? v[j] : 0.f) / (1e-4f + sqrtf(ss) * rsd);
+            const bool is_q = (NJ == 3 && j == 0);
+            const bool is_k = (NJ == 3) ? (j == 1) : (j == 0);
             if (is_q) {
                 if (ok) a.q[(bhq * a.s + s) * D + d] = y * a.qscale;
                 continue;
@@ -583,11 +599,9 @@ __global__ __launch_bounds__(256) void qkv_split_x3_k(const SplitXK a) {
             const unsigned lo = bf16_rn_bits(y - __uint_as_float(hi << 16));
             const int key = kbase + s;
             if (is_k) {
-                if (ok) {
-                    unsigned short* kp = a.k + ((bhq * a.klp + key) * D + (d & ~7)) * 2 + (d & 7);
-                    kp[0] = (unsigned short)hi;
-                    kp[8] = (unsigned short)lo;
-                }
+                unsigned short* kp = sk + (pp * D + (d & ~7)) * 2 + (d & 7);
+                kp[0] = (unsigned short)hi;
+                kp[8] = (unsigned short)lo;
             } else if (fast) {
                 const int lp = perm16(pp);                       // tile start is 16-aligned: permute locally
                 sv[(d * 2 + 0) * 64 + lp] = (unsigned short)hi;
@@ -599,10 +613,17 @@ __global__ __launch_bounds__(256) void qkv_split_x3_k(const SplitXK a) {
             }
         }
     }
+    __syncthreads();
+    const int nvalid = min(64, a.s - s0);
+    // K: nvalid consecutive keys x D*4 bytes are one contiguous run of the K buffer
+    {
+        constexpr int UPK = D / 4;                               // 16-byte units per key
+        uint4* kdst = reinterpret_cast<uint4*>(a.k + (bhq * a.klp + kbase + s0) * D * 2);
+        const uint4* ksrc = reinterpret_cast<const uint4*>(sk);
+        for (int idx = t; idx < nvalid * UPK; idx += 256) kdst[idx] = ksrc[idx];
+    }
     if (fast) {
-        __syncthreads();
-        // D*2 rows of 64 positions = 8 units of 16 B each
-        const int nvalid = min(64, a.s - s0);                   // multiple of 16 when fast (s % 16 == 0 then)
+        // D*2 rows of 64 positions = 8 units of 16 B each (nvalid is a multiple of 16 here)
         for (int idx = t; idx < D * 2 * 8; idx += 256) {
             const int rowi = idx >> 3, ku = idx & 7;
             if (ku * 8 >= nvalid) continue;
@@ -631,8 +652,10 @@ extern "C" int vh_qkv_split_x3(vh_ctx* ctx, const vh_qkv_split_args* p) {
     const int d = a.d;
     const double bytes = 8.0 * (double)a.rows * a.s * a.heads * a.d * a.nj;
     return vh_dispatch(ctx, VH_TAG_QKVSPLIT, 0.0, bytes, [k, d, nblk](hipStream_t s) -> int {
-        if (d == 64) hipLaunchKernelGGL(qkv_split_x3_k<64>, dim3((unsigned)nblk), dim3(256), 0, s, k);
-        else hipLaunchKernelGGL(qkv_split_x3_k<32>, dim3((unsigned)nblk), dim3(256), 0, s, k);
+        if (d == 64 && k.nj == 3) hipLaunchKernelGGL((qkv_split_x3_k<64, 3>), dim3((unsigned)nblk), dim3(256), 0, s, k);
+        else if (d == 64) hipLaunchKernelGGL((qkv_split_x3_k<64, 2>), dim3((unsigned)nblk), dim3(256), 0, s, k);
+        else if (k.nj == 3) hipLaunchKernelGGL((qkv_split_x3_k<32, 3>), dim3((unsigned)nblk), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((qkv_split_x3_k<32, 2>), dim3((unsigned)nblk), dim3(256), 0, s, k);
         return vh_check_launch("qkv_split_x3_k");
     });
 }
