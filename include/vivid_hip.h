@@ -107,7 +107,19 @@ enum { VH_PREC_F32 = 0, VH_PREC_BF16X3 = 1 };
  * with split=1.  Scaling, mp_silu and the mp_cat concat are applied by the producer of the S8 tensor. */
 enum { VH_CONV_TILE128 = 0, VH_CONV_GLDS256 = 1 };   /* 128x128 register-staged tile | 256-wide direct-to-LDS tile */
 enum { VH_PRO_NONE = 0, VH_PRO_SILU = 1 };
-enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2 };
+enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2, VH_EPI_QKV = 3 };
+/* VH_EPI_QKV (1x1 conv, VH_CONV_GLDS256): the attn_qkv / x_attn_kv convolution writes the attention operands itself
+ * instead of an fp32 tensor that vh_qkv_split_x3 would read back: per pixel and head, q / k / v are RMS-normalised
+ * over their 64 channels (normalize(dim=2), training/models.py:192-194, :279-293) in the accumulators and stored as
+ * vh_qkv_split_x3 stores them (same formats, same buffers, same arguments).  The OUTPUT CHANNELS of the weight must be
+ * ordered [head][j][d] (o' = (head*nj + j)*64 + d) instead of the reference's (head*64 + d)*nj + j, so that a wave's
+ * 64-column accumulator slab is one (head, j): permute the rows of w before vh_prep_weight.
+ * Requires d == 64, s % 32 == 0, koff % 16 == 0, cout == heads*64*nj, out == NULL. */
+typedef struct {
+    float* q; void* k; void* v;            /* as vh_qkv_split_args (q unused for nj == 2) */
+    int heads, nj, rows_per_b, koff, kl;   /* s = h*w of the convolution; rows = its rows */
+    float qscale;
+} vh_qkv_epilogue;
 typedef struct {
     const float* src0; const float* src1;  /* src1 may be NULL */
     int c0, c1;                            /* channels of each source (multiples of 4) */
@@ -130,6 +142,7 @@ typedef struct {
     const float* cvec; int cvec_ld;        /* SCALE_SILU: cvec[row*cvec_ld + o] */
     const float* res; int res_up;          /* MPSUM */
     float ta, tb, clip;                    /* clip <= 0: no clipping */
+    const vh_qkv_epilogue* qkv;            /* VH_EPI_QKV only */
 } vh_conv_args;
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
 

@@ -31,7 +31,7 @@ def test_struct_mirrors_match_header_field_counts():
              "vh_qkv_split_args": _lib.QkvSplitArgs, "vh_split_args": _lib.SplitArgs, "vh_attention_args": _lib.AttentionArgs, "vh_embed_args": _lib.EmbedArgs,
              "vh_linear_args": _lib.LinearArgs, "vh_segment": _lib.Segment, "vh_assemble_args": _lib.AssembleArgs,
              "vh_precond_out_args": _lib.PrecondOutArgs, "vh_warp_args": _lib.WarpArgs,
-             "vh_sampler_step_args": _lib.SamplerStepArgs, "vh_codec_args": _lib.CodecArgs, "vh_add_depth_args": _lib.AddDepthArgs, "vh_resize_args": _lib.ResizeArgs}
+             "vh_sampler_step_args": _lib.SamplerStepArgs, "vh_qkv_epilogue": _lib.QkvEpilogue, "vh_codec_args": _lib.CodecArgs, "vh_add_depth_args": _lib.AddDepthArgs, "vh_resize_args": _lib.ResizeArgs}
     for cname, st in pairs.items():
         m = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + r"\s*;", h, flags=re.S)
         assert m, cname

@@ -3,6 +3,7 @@
 
 Tolerances: fp32 kernels 2e-5 rel-L2 (summation order, hardware exp2/rcp); bf16x3 kernels 1e-4
 (hi/lo split drops ~2^-16 of each product) — both far inside north_star's 1e-3."""
+import ctypes
 import math
 
 import pytest
@@ -211,6 +212,78 @@ def test_qkv_split_and_attention(ctx, x3, b, heads, s, kl, d, nz):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert rel_l2(out.cpu(), ref.permute(0, 2, 1)) < (1e-4 if x3 else 2e-5)
+
+
+@pytest.mark.parametrize("rows,nsrc,hw,heads,cin,koff_extra", [(2, 1, (8, 8), 2, 64, 0), (1, 1, (16, 16), 3, 96, 0), (4, 2, (8, 4), 1, 64, 0),
+                                                              (2, 1, (32, 32), 4, 256, 0)])
+def test_conv_qkv_epilogue_matches_split_kernel(ctx, rows, nsrc, hw, heads, cin, koff_extra):
+    """VH_EPI_QKV: the 1x1 attn_qkv / x_attn_kv convolution writes q, k (S8) and v^T itself.  Checked against the
+    unfused pair it replaces on the same inputs: vh_conv (fp32 out) -> vh_qkv_split_x3, buffer for buffer
+    (normalize(dim=2)/unbind/concat of models.py:192-194, :279-297)."""
+    from vivid_amd import _lib as L
+    h, w = hw
+    S, D = h * w, 64
+    g = torch.Generator().manual_seed(rows * 31 + cin + heads)
+    for nj, rpb in ((3, 1), (2, nsrc)):
+        if nj == 2 and rows % rpb:
+            continue
+        cout = heads * D * nj
+        x = torch.randn(rows, cin, h, w, generator=g)
+        wgt = torch.randn(cout, cin, 1, 1, generator=g)
+        M = rows * S
+        xs8 = torch.empty(M * cin, device="cuda")
+        xd = _nhwc(x).cuda()
+        ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin,
+                                         out=xs8.data_ptr(), out_raw=None))
+        b = rows // rpb
+        koff = 0 if nj == 3 else S                                  # cross keys sit behind the S self keys
+        kl = koff + rpb * S
+        klp = (kl + 63) // 64 * 64
+        qscale = LOG2E / math.sqrt(D) if nj == 3 else 1.0
+
+        def conv(wmat, epi, out, qkv):
+            wt, cin_pad, k_pad = _prep(ctx, wmat.cuda(), 1, split=2)
+            ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                          taps=1, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                          scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=out, out_s8=None, out_s8_c=0,
+                                          prec=1, kernel=1, epi=epi, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0,
+                                          qkv=ctypes.addressof(qkv) if qkv is not None else None))
+            torch.cuda.synchronize()
+
+        bufs = {}
+        for mode in ("split", "fused"):
+            Q = torch.full((b * heads * S * D,), 7.0, device="cuda")
+            K = torch.full((b * heads * klp * D,), 7.0, device="cuda")
+            V = torch.full((b * heads * klp * D,), 7.0, device="cuda")
+            if mode == "split":
+                out = torch.empty(M, cout, device="cuda")
+                conv(wgt, 0, out.data_ptr(), None)
+                ctx.call("vh_qkv_split_x3", L.QkvSplitArgs(inp=out.data_ptr(), rows=rows, s=S, heads=heads, d=D, nj=nj, rows_per_b=rpb, koff=koff,
+                                                          kl=kl, qscale=qscale, q=Q.data_ptr() if nj == 3 else None, k=K.data_ptr(), v=V.data_ptr()))
+            else:
+                wperm = wgt.view(heads, D, nj, cin, 1, 1).transpose(1, 2).contiguous().view(cout, cin, 1, 1)   # [head][j][d] rows
+                e = L.QkvEpilogue(q=Q.data_ptr() if nj == 3 else None, k=K.data_ptr(), v=V.data_ptr(), heads=heads, nj=nj, rows_per_b=rpb,
+                                  koff=koff, kl=kl, qscale=qscale)
+                conv(wperm, 3, None, e)
+            torch.cuda.synchronize()
+            bufs[mode] = (Q.cpu(), K.cpu(), V.cpu())
+        for name, a_, b_ in zip("qkv", bufs["split"], bufs["fused"]):
+            if name == "q":
+                if nj == 3:
+                    assert rel_l2(b_, a_) < 2e-6, (nj, name)
+                continue
+            # bf16 hi/lo pairs: compare the values they encode (hi + lo); untouched pads stay 7.0 in both
+            da = _s8_like_decode(a_, name, b * heads, klp, D)
+            db = _s8_like_decode(b_, name, b * heads, klp, D)
+            assert torch.isfinite(db).all() and rel_l2(db, da) < 2e-6, (nj, name)
+
+
+def _s8_like_decode(buf, which, bh, klp, D):
+    """K ([bh][klp][D/8][hi8|lo8]) or V^T ([bh][D][hl][klp]) operand buffer -> hi + lo as fp32."""
+    f = (buf.view(torch.int16).to(torch.int32) << 16).view(torch.float32)
+    if which == "k":
+        return f.view(bh, klp, D // 8, 2, 8).sum(dim=3)
+    return f.view(bh, D, 2, klp).sum(dim=2)
 
 
 @pytest.mark.parametrize("s,kl", [(64, 448), (256, 448), (256, 512), (200, 1000)])

@@ -26,6 +26,11 @@ class PrepWeightArgs(C.Structure):
                 ("split", C.c_int)]
 
 
+class QkvEpilogue(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("heads", C.c_int), ("nj", C.c_int),
+                ("rows_per_b", C.c_int), ("koff", C.c_int), ("kl", C.c_int), ("qscale", C.c_float)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
                 ("scale0", C.c_float), ("scale1", C.c_float),
@@ -35,7 +40,7 @@ class ConvArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
                 ("prec", C.c_int), ("kernel", C.c_int), ("epi", C.c_int),
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
-                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float)]
+                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p)]
 
 
 class PixnormArgs(C.Structure):

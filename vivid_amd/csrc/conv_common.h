@@ -19,6 +19,8 @@ struct ConvK {
     const float* res; int res_up;
     float ta, tb, clip;
     int M, HW, NT;
+    // VH_EPI_QKV: attention operand buffers and the key-sequence placement of vh_qkv_split_x3
+    float* q; unsigned short* qk; unsigned short* qv; int q_heads, q_nj, q_rows_per_b, q_koff, q_klp; float q_scale;
     int ksplit; float* scratch;     // split-K: this launch covers K-tiles [ks*KT/ksplit, (ks+1)*KT/ksplit) and
                                     // writes raw partial sums to scratch[ks][M][cout]; a reducer applies the epilogue
 };

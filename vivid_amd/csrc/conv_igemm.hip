@@ -234,7 +234,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_conv: null args");
     const vh_conv_args a = *p;
     VH_REQUIRE(a.taps == 1 || a.taps == 9, "vh_conv: taps must be 1 or 9 (got %d)", a.taps);
-    VH_REQUIRE(a.src0 && a.wt && (a.out || a.out_s8), "vh_conv: null tensor");
+    VH_REQUIRE(a.src0 && a.wt && (a.out || a.out_s8 || a.epi == VH_EPI_QKV), "vh_conv: null tensor");
     VH_REQUIRE(a.prec == VH_PREC_F32 || a.prec == VH_PREC_BF16X3, "vh_conv: bad prec %d", a.prec);
     if (a.prec == VH_PREC_BF16X3) {
         VH_REQUIRE(!a.src1 && a.pro == VH_PRO_NONE && a.scale0 == 1.0f, "vh_conv: bf16x3 takes one pre-split (S8) source; scale/silu/concat belong to its producer");
@@ -250,7 +250,16 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.wt), "vh_conv: source/weight pointers must be 16-byte aligned");
     VH_REQUIRE(!a.up || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: up needs even output size");
     VH_REQUIRE(a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU, "vh_conv: bad prologue");
-    VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_MPSUM, "vh_conv: bad epilogue");
+    VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_QKV, "vh_conv: bad epilogue");
+    if (a.epi == VH_EPI_QKV) {
+        VH_REQUIRE(a.qkv && a.taps == 1 && a.kernel == VH_CONV_GLDS256 && !a.out && !a.out_s8, "vh_conv: QKV epilogue needs qkv args, a 1x1 GLDS convolution and no other output");
+        const vh_qkv_epilogue& e = *a.qkv;
+        VH_REQUIRE((e.nj == 2 || (e.nj == 3 && e.q)) && e.k && e.v, "vh_conv: QKV epilogue: nj must be 2 or 3 (3 needs q), k and v given");
+        VH_REQUIRE(e.heads > 0 && a.cout == e.heads * 64 * e.nj, "vh_conv: QKV epilogue: cout %d != heads*64*nj", a.cout);
+        VH_REQUIRE((a.h * a.w) % 32 == 0 && e.koff % 16 == 0 && e.koff >= 0, "vh_conv: QKV epilogue needs h*w %% 32 == 0 and koff %% 16 == 0");
+        VH_REQUIRE(e.rows_per_b > 0 && a.rows % e.rows_per_b == 0 && e.koff + e.rows_per_b * a.h * a.w <= e.kl, "vh_conv: QKV epilogue: keys do not fit");
+        VH_REQUIRE(vh_aligned16(e.q) && vh_aligned16(e.k) && vh_aligned16(e.v), "vh_conv: QKV epilogue: pointers must be 16-byte aligned");
+    }
     VH_REQUIRE(a.epi != VH_EPI_SCALE_SILU || (a.cvec && a.cvec_ld >= a.cout), "vh_conv: SCALE_SILU needs cvec with ld >= cout");
     VH_REQUIRE(a.epi != VH_EPI_MPSUM || a.res, "vh_conv: MPSUM needs res");
     VH_REQUIRE(!(a.epi == VH_EPI_MPSUM && a.res_up) || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: res_up needs even output size");
@@ -267,6 +276,12 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
     k.ksplit = 1; k.scratch = nullptr;
+    k.q = nullptr; k.qk = k.qv = nullptr; k.q_heads = k.q_nj = k.q_rows_per_b = k.q_koff = k.q_klp = 0; k.q_scale = 1.f;
+    if (a.epi == VH_EPI_QKV) {
+        const vh_qkv_epilogue& e = *a.qkv;
+        k.q = e.q; k.qk = static_cast<unsigned short*>(e.k); k.qv = static_cast<unsigned short*>(e.v);
+        k.q_heads = e.heads; k.q_nj = e.nj; k.q_rows_per_b = e.rows_per_b; k.q_koff = e.koff; k.q_klp = (e.kl + 63) / 64 * 64; k.q_scale = e.qscale;
+    }
     VH_REQUIRE(!a.scratch || vh_aligned16(a.scratch), "vh_conv: scratch must be 16-byte aligned");
     const int taps = a.taps, prec = a.prec;
     const unsigned grid = (unsigned)(MT * NT);

@@ -236,6 +236,98 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
 
     // the loop's last barrier has retired every read of the stages: reuse sA as 8 per-wave transpose patches
     float* patch = reinterpret_cast<float*>(&sA[0][0]) + w * (32 * 36);
+    if constexpr (TAPS == 1 && M16 && NI == 2) {
+        if (a.epi == VH_EPI_QKV) {
+            // Fused q/k/v split (see VH_EPI_QKV in vivid_hip.h).  This wave's 64 accumulator columns are one (head, j).
+            const int slab = (n0 + wn * 64) >> 6;
+            if (slab * 64 >= a.cout) return;
+            const int head = slab / a.q_nj, j = slab - head * a.q_nj;
+            const bool is_q = a.q_nj == 3 && j == 0, is_k = a.q_nj == 3 ? j == 1 : j == 0;
+            // 1. RMS-normalise every pixel row over the 64 channels, in the accumulators (C/D map: column = lane&15 of each of
+            //    the 4 column tiles, row = 4*(lane>>4) + r): square-sum over the 4 tiles, then over the 16 lanes of the row.
+#pragma unroll
+            for (int mt = 0; mt < MI * 2; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) ss += acc16[mt][ntl][r] * acc16[mt][ntl][r];
+                    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+                    const float sc = (is_q ? a.q_scale : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);     // 0.125 = 1/sqrt(64)
+#pragma unroll
+                    for (int ntl = 0; ntl < 4; ++ntl) acc16[mt][ntl][r] *= sc;
+                }
+            }
+            // 2. per 32x32 block: through the wave's LDS patch, then rows (q, k) or columns (v^T) of it go out as 16-byte units
+            const int S = a.HW;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int row0 = m0 + (wm * MI + mi) * 32;
+                    if (row0 >= a.M) continue;                              // (M % 32 == 0: blocks are all-in or all-out)
+                    constexpr int LD = 36;
+                    {
+                        const int c = l & 15, rb = (l >> 4) * 4;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            patch[(rb + r) * LD + c] = acc16[2 * mi][2 * ni][r];
+                            patch[(rb + r) * LD + 16 + c] = acc16[2 * mi][2 * ni + 1][r];
+                            patch[(16 + rb + r) * LD + c] = acc16[2 * mi + 1][2 * ni][r];
+                            patch[(16 + rb + r) * LD + 16 + c] = acc16[2 * mi + 1][2 * ni + 1][r];
+                        }
+                    }
+                    const int rowi = row0 / S, s0 = row0 - rowi * S;           // 32 | S: the block lies inside one image
+                    const int bb = rowi / a.q_rows_per_b, seg = rowi - bb * a.q_rows_per_b;
+                    const size_t bhq = (size_t)bb * a.q_heads + head;
+                    const int key0 = a.q_koff + seg * S + s0;                  // multiple of 16
+                    if (is_q || is_k) {
+                        const int cg = l & 7, rsub = l >> 3;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int rl = rsub + 8 * i;
+                            const float4 v = *reinterpret_cast<const float4*>(&patch[rl * LD + 4 * cg]);
+                            const int d0 = ni * 32 + 4 * cg;
+                            if (is_q) {
+                                *reinterpret_cast<float4*>(a.q + (bhq * S + s0 + rl) * 64 + d0) = v;
+                            } else {
+                                const float y[4] = {v.x, v.y, v.z, v.w};
+                                unsigned h[4], lo[4];
+#pragma unroll
+                                for (int e2 = 0; e2 < 4; ++e2) {
+                                    h[e2] = bf16_rn_bits(y[e2]);
+                                    lo[e2] = bf16_rn_bits(y[e2] - __uint_as_float(h[e2] << 16));
+                                }
+                                unsigned short* kp = a.qk + ((bhq * a.q_klp + key0 + rl) * 64 + (d0 & ~7)) * 2 + (d0 & 7);
+                                *reinterpret_cast<uint2*>(kp) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                                *reinterpret_cast<uint2*>(kp + 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                            }
+                        }
+                    } else {
+                        // V^T [bh][d][hl][klp], positions permuted inside 16-key groups (bits 2,3 swapped): lane = channel c and
+                        // half the block's 4 units of 8 positions
+                        const int c = l & 31, d = ni * 32 + c;
+#pragma unroll
+                        for (int uu = 0; uu < 2; ++uu) {
+                            const int unit = (l >> 5) * 2 + uu;                // 8 positions 8*unit .. of the 32-key block
+                            unsigned h[8], lo[8];
+#pragma unroll
+                            for (int e2 = 0; e2 < 8; ++e2) {
+                                const int pos = unit * 8 + e2;
+                                const int key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+                                const float y = patch[key * LD + c];
+                                h[e2] = bf16_rn_bits(y);
+                                lo[e2] = bf16_rn_bits(y - __uint_as_float(h[e2] << 16));
+                            }
+                            unsigned short* vp = a.qv + ((bhq * 64 + d) * 2) * (size_t)a.q_klp + key0 + unit * 8;
+                            *reinterpret_cast<uint4*>(vp) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+                            *reinterpret_cast<uint4*>(vp + a.q_klp) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
+                        }
+                    }
+                }
+            return;
+        }
+    }
     ConvK e = a;
     if (a.ksplit > 1) {                                    // raw partial sums; vh_conv's reducer applies the epilogue
         e.epi = VH_EPI_STORE;
@@ -292,7 +384,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // `ksplit` workgroups per tile, partial sums through a scratch slab, epilogue in a small reducer launch
     const int KTall = a.k_pad / BK;
     int ksplit = 1;
-    if (a.scratch && MT * NT < 192 && KTall >= 16) {
+    if (a.scratch && MT * NT < 192 && KTall >= 16 && a.epi != VH_EPI_QKV) {
         ksplit = (int)std::min<long long>(std::min<long long>(8, (383 + MT * NT) / (MT * NT)), KTall / 8);
         while (ksplit > 1 && (size_t)ksplit * (size_t)M * a.cout > a.scratch_floats) --ksplit;
     }
@@ -303,6 +395,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
     const int cfg = tall ? 2 : wide ? 1 : 0;
     const bool use16 = m16;
+    if (a.epi == VH_EPI_QKV && !use16) return vh_fail(VH_EINVAL, "vh_conv: the QKV epilogue exists only in the 16x16x32-MFMA kernels (unset VIVID_CONV_MFMA)");
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, use16, grid](hipStream_t s) -> int {
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, M16_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, M16_>), dim3(grid), dim3(512), 0, s, k)
 #define VH_LAUNCH_CFG(T, M16_)                                  \

@@ -12,6 +12,7 @@ in one fp32 workspace tensor as NHWC buffers handed out by :class:`Arena`.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -122,6 +123,8 @@ class Engine:
         # replay each recorded evaluation as one hipGraph: measured null on MI355X (15.1 vs 15.2 ms at batch 1, 376.7 vs
         # 377.4 ms at the headline workload: replay is GPU-bound, not launch-bound), so opt-in only
         self.use_graph = os.environ.get("VIVID_HIPGRAPH", "0") == "1"
+        # attn_qkv / x_attn_kv write q, k, v^T from their own epilogue (needs the 16x16x32-MFMA glds kernel)
+        self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0" and os.environ.get("VIVID_CONV_MFMA", "16") != "32"
         self.cfg = cfg
         self.dual = dual_source
         self.nsrc = 2 if dual_source else 1
@@ -185,10 +188,11 @@ class Engine:
                 if b.cin != b.cout:
                     self._prep_conv(p + "conv_skip.weight", 1)
                 if b.heads:
-                    self._prep_conv(p + "attn_qkv.weight", 1)
+                    fused = self._qkv_fused(b)
+                    self._prep_conv(p + "attn_qkv.weight", 1, qkv_perm=3 if fused else 0)
                     self._prep_conv(p + "attn_proj.weight", 1)
                     if b.xattn:
-                        self._prep_conv(p + "x_attn_kv.weight", 1)
+                        self._prep_conv(p + "x_attn_kv.weight", 1, qkv_perm=2 if fused else 0)
                 w = params[p + "emb_linear.weight"]
                 a = L.PrepWeightArgs(w=w.data_ptr(), cout=b.cout, cin=spec.cemb, taps=1, cin_pad=_round_up(spec.cemb, 4),
                                      k_pad=kpad, gain_ptr=params[p + "emb_gain"].data_ptr(), gain_value=1.0,
@@ -201,8 +205,19 @@ class Engine:
                 self._prep_conv(prefix + "out_conv.weight", 9, gain=params[prefix + "out_gain"])
         self._prep_linear("logvar_linear.weight")
 
-    def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None):
+    def _qkv_fused(self, b: BlockSpec) -> bool:
+        """attn_qkv / x_attn_kv write the attention operands from their own epilogue (VH_EPI_QKV) instead of an fp32
+        tensor that vh_qkv_split_x3 reads back: bf16x3 glds path, 64-channel heads, 32 | pixels per image."""
+        if not (self.x3 and self.glds and self.fuse_qkv and b.heads):
+            return False
+        return b.cout % 32 == 0 and b.cin % 32 == 0 and b.cout // b.heads == 64 and (b.res * b.res) % 32 == 0
+
+    def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None, qkv_perm: int = 0):
         w = self._params[key]
+        if qkv_perm and w.numel():
+            # output channel (head*64 + d)*nj + j  ->  (head*nj + j)*64 + d: one (head, j) per 64-column accumulator slab
+            nj, heads = qkv_perm, w.shape[0] // (64 * qkv_perm)
+            w = w.view(heads, 64, nj, *w.shape[1:]).transpose(1, 2).contiguous().view(w.shape)
         cout, cin = w.shape[0], w.shape[1]
         # 2-D (linear) weights feed embed_k/linear_k: never split.  bf16x3 convs: split 2 = [cout][K] for the glds kernel
         split = (2 if self.glds else 1) if (self.x3 and w.ndim == 4) else 0
@@ -272,13 +287,16 @@ class Engine:
 
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
               cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0,
-              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False):
+              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False, qkv=None):
         """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8;
-        also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned."""
+        also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned.
+        qkv (L.QkvEpilogue): the result goes straight into attention operand buffers (VH_EPI_QKV); nothing is returned."""
         out_s8 = None
-        if s8_only or also_s8:
+        if qkv is not None:
+            epi = L_EPI_QKV
+        if (s8_only or also_s8) and qkv is None:
             out_s8 = self._alloc(rows, h, w, W.cout)
-        if not s8_only and out is None:
+        if not s8_only and out is None and qkv is None:
             out = self._alloc(rows, h, w, W.cout)
         s0, sc0 = srcs[0]
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
@@ -292,8 +310,11 @@ class Engine:
                        out=out.ptr if out is not None else None, out_s8=out_s8.ptr if out_s8 is not None else None,
                        out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, kernel=1 if (prec and self.glds) else 0, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
-                       res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip)
+                       res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip,
+                       qkv=C.addressof(qkv) if qkv is not None else None)
         self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}")
+        if qkv is not None:
+            return None
         if also_s8:
             return out, out_s8
         return out_s8 if s8_only else out
@@ -415,32 +436,46 @@ class Engine:
             use_feat = b.xattn and feat is not None
             kl = S * (1 + self.nsrc) if use_feat else S
             nz = n_zero * S if (b.xattn and not use_feat) else 0.0
-            if ax3:
-                qkv = self._conv([(r_s8, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R, prec=1)
-                self._free(r_s8)
-            else:
-                qkv = self._conv([(out, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R)
+            fused = ax3 and self._qkv_fused(b)
             klp = _round_up(kl, 64) if ax3 else kl            # bf16x3: K as S8, V transposed, keys padded to 64
             split_op, attn_op = ("vh_qkv_split_x3", "vh_attention_x3") if ax3 else ("vh_qkv_split", "vh_attention")
             q = self._alloc(rows, b.heads, S, D)
             k = self._alloc(rows, b.heads, klp, D)
             v = self._alloc(rows, b.heads, klp, D)
-            self._call(split_op, L.QkvSplitArgs(inp=qkv.ptr, rows=rows, s=S, heads=b.heads, d=D, nj=3, rows_per_b=1,
-                                                koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
-            self._free(qkv)
+            if fused:
+                self._conv([(r_s8, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R, prec=1,
+                           qkv=L.QkvEpilogue(q=q.ptr, k=k.ptr, v=v.ptr, heads=b.heads, nj=3, rows_per_b=1, koff=0, kl=kl,
+                                             qscale=LOG2E / math.sqrt(D)))
+                self._free(r_s8)
+            else:
+                if ax3:
+                    qkv = self._conv([(r_s8, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R, prec=1)
+                    self._free(r_s8)
+                else:
+                    qkv = self._conv([(out, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R)
+                self._call(split_op, L.QkvSplitArgs(inp=qkv.ptr, rows=rows, s=S, heads=b.heads, d=D, nj=3, rows_per_b=1,
+                                                    koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
+                self._free(qkv)
             if use_feat:
                 if ax3:
                     fs, own = feat_s8, False
                     if fs is None:
                         fs, own = self._split([(feat, 1.0)], 0), True
-                    kv = self._conv([(fs, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R, prec=1)
+                    if fused:
+                        self._conv([(fs, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R, prec=1,
+                                   qkv=L.QkvEpilogue(q=None, k=k.ptr, v=v.ptr, heads=b.heads, nj=2, rows_per_b=self.nsrc,
+                                                     koff=S, kl=kl, qscale=1.0))
+                        kv = None
+                    else:
+                        kv = self._conv([(fs, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R, prec=1)
                     if own:
                         self._free(fs)
                 else:
                     kv = self._conv([(feat, 1.0)], self.W[p + "x_attn_kv.weight"], rows * self.nsrc, R, R)
-                self._call(split_op, L.QkvSplitArgs(inp=kv.ptr, rows=rows * self.nsrc, s=S, heads=b.heads, d=D, nj=2,
-                                                    rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0, q=None, k=k.ptr, v=v.ptr))
-                self._free(kv)
+                if kv is not None:
+                    self._call(split_op, L.QkvSplitArgs(inp=kv.ptr, rows=rows * self.nsrc, s=S, heads=b.heads, d=D, nj=2,
+                                                        rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0, q=None, k=k.ptr, v=v.ptr))
+                    self._free(kv)
             att = self._alloc(rows, R, R, C)
             self._call(attn_op, L.AttentionArgs(q=q.ptr, k=k.ptr, v=v.ptr, b=rows, heads=b.heads, s=S, kl=kl, d=D,
                                                 n_zero_keys=nz, out=att.ptr, out_s8=1 if ax3 else 0,
@@ -684,3 +719,4 @@ class Engine:
 L_PRO_SILU = 1
 L_EPI_SCALE_SILU = 1
 L_EPI_MPSUM = 2
+L_EPI_QKV = 3
