@@ -131,6 +131,80 @@ __global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long np
     }
 }
 
+// Register-resident form for c <= 512: a wave takes PPW pixels, issues all of their loads up front (the one-pixel-per-wave
+// form above has one dependent load -> reduce -> store chain per wave: latency-bound) and reads every value once.
+template <int NV, bool POOL, int PPW>
+__global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long long npix) {
+    const long long p0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
+    if (p0 >= npix) return;
+    const int lane = threadIdx.x & 63;
+    const int c4 = a.c >> 2;
+    float4 v[PPW][NV];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const long long p = p0 + q < npix ? p0 + q : npix - 1;
+        const float4* s0;
+        size_t o1 = 0, o2 = 0, o3 = 0;
+        if (POOL) {
+            const int hw = a.h * a.w;
+            const int img = (int)(p / hw), rem = (int)(p - (long long)img * hw);
+            const int y = rem / a.w, x = rem - y * a.w;
+            const int wi = 2 * a.w;
+            const size_t base = ((size_t)img * 2 * a.h + 2 * y) * wi + 2 * x;
+            s0 = reinterpret_cast<const float4*>(a.in + base * a.c);
+            o1 = (size_t)c4; o2 = (size_t)wi * c4; o3 = o2 + c4;
+        } else {
+            s0 = reinterpret_cast<const float4*>(a.in + (size_t)p * a.c);
+        }
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int i = lane + 64 * n;
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < c4) {
+                t = s0[i];
+                if (POOL) {
+                    const float4 b = s0[i + o1], c = s0[i + o2], d = s0[i + o3];
+                    t.x = 0.25f * (t.x + b.x + c.x + d.x); t.y = 0.25f * (t.y + b.y + c.y + d.y);
+                    t.z = 0.25f * (t.z + b.z + c.z + d.z); t.w = 0.25f * (t.w + b.w + c.w + d.w);
+                }
+            }
+            v[q][n] = t;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const long long p = p0 + q;
+        float scale = 1.f;
+        if (a.norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int n = 0; n < NV; ++n) ss += v[q][n].x * v[q][n].x + v[q][n].y * v[q][n].y + v[q][n].z * v[q][n].z + v[q][n].w * v[q][n].w;
+            ss = wave_sum(ss);
+            scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
+        }
+        if (p >= npix) continue;
+        float4* dst = reinterpret_cast<float4*>(a.out + (size_t)p * a.c);
+        unsigned short* s8 = a.out_s8 ? static_cast<unsigned short*>(a.out_s8) + (size_t)p * a.c * 2 : nullptr;
+#pragma unroll
+        for (int n = 0; n < NV; ++n) {
+            const int i = lane + 64 * n;
+            if (i >= c4) continue;
+            float4 t = v[q][n];
+            t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
+            dst[i] = t;
+            if (s8) {
+                const float e[4] = {mp_silu_dev(t.x), mp_silu_dev(t.y), mp_silu_dev(t.z), mp_silu_dev(t.w)};
+                unsigned h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) split_bf16(e[j], h[j], l[j]);
+                unsigned short* qd = s8 + (size_t)(i >> 1) * 16 + (i & 1) * 4;
+                *reinterpret_cast<uint2*>(qd) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(qd + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- fp32 -> S8 split (+concat, scale, silu)
 // one thread per 8-channel chunk of one pixel
 __global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total) {
@@ -484,7 +558,17 @@ extern "C" int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* p) {
     VH_REQUIRE(!a.out_s8 || a.c % 32 == 0, "vh_pixnorm: S8 output needs c %% 32 == 0 (got %d)", a.c);
     const long long npix = (long long)a.rows * a.h * a.w;
     return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * ((a.pool ? 5.0 : 2.0) + (a.out_s8 ? 1.0 : 0.0)), [a, npix](hipStream_t s) -> int {
-        hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
+        const int c4 = a.c >> 2;
+        const bool inplace_pool = a.pool && a.in == a.out;       // (never used by the engine; the register form reads neighbours late)
+        if (c4 <= 64 && !inplace_pool) {
+            if (a.pool) hipLaunchKernelGGL((pixnorm_reg_k<1, true, 2>), dim3(blocks_for(npix, 8)), dim3(256), 0, s, a, npix);
+            else hipLaunchKernelGGL((pixnorm_reg_k<1, false, 4>), dim3(blocks_for(npix, 16)), dim3(256), 0, s, a, npix);
+        } else if (c4 <= 128 && !inplace_pool) {
+            if (a.pool) hipLaunchKernelGGL((pixnorm_reg_k<2, true, 2>), dim3(blocks_for(npix, 8)), dim3(256), 0, s, a, npix);
+            else hipLaunchKernelGGL((pixnorm_reg_k<2, false, 4>), dim3(blocks_for(npix, 16)), dim3(256), 0, s, a, npix);
+        } else {
+            hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
+        }
         return vh_check_launch("pixnorm_k");
     });
 }
