@@ -95,7 +95,84 @@ def test_sr_cascade_runs():
     assert out[0].noise.shape == (4, 3, 32, 32)
 
 
-def test_pickle_paths_are_refused():
+def test_urls_are_refused():
     from vivid_amd.generate import generate_images_nvs
     with pytest.raises(NotImplementedError, match="needs the network"):
         generate_images_nvs("https://example.invalid/vivid-base.pkl", data=[])
+
+
+def _write_snapshot_like(path, cfg, sd):
+    """A file with the structure of the reference's network-snapshot-*.pkl (training_loop.py:485-496), written WITHOUT the
+    reference: stand-in modules named like the reference's supply the globals the pickle stream names."""
+    import pickle
+    import sys
+    import types
+
+    class EasyDict(dict):
+        pass
+
+    def _reconstruct_persistent_obj(meta):       # never called here: only its qualified name goes into the stream
+        raise AssertionError
+
+    class Rec:
+        def __init__(self, meta):
+            self.meta = meta
+
+        def __reduce__(self):
+            return (_reconstruct_persistent_obj, (self.meta,))
+
+    def module_tree(prefix_items):
+        """nested {_parameters, _buffers, _modules} dicts from dotted names"""
+        root = dict(_parameters={}, _buffers={}, _modules={}, _non_persistent_buffers_set=set())
+        for name, t in prefix_items:
+            node = root
+            parts = name.split(".")
+            for p in parts[:-1]:
+                if p not in node["_modules"]:
+                    node["_modules"][p] = Rec(dict(type="class", version=6, module_src="raise SystemExit('executed')", class_name="Sub",
+                                                   state=dict(_parameters={}, _buffers={}, _modules={}, _non_persistent_buffers_set=set())))
+                node = node["_modules"][p].meta["state"]
+            node["_parameters"][parts[-1]] = torch.nn.Parameter(t.to(torch.float16), requires_grad=False)
+        return root
+
+    kw = cfg.to_dict()
+    for k in ("precision",):
+        kw.pop(k, None)
+    state = module_tree(sd.items())
+    state.update(_init_args=[], _init_kwargs=kw)
+    top = Rec(dict(type="class", version=6, module_src="raise SystemExit('executed')", class_name="NVPrecond", state=state))
+    fake = {"torch_utils": types.ModuleType("torch_utils"), "torch_utils.persistence": types.ModuleType("torch_utils.persistence"),
+            "dnnlib": types.ModuleType("dnnlib"), "dnnlib.util": types.ModuleType("dnnlib.util")}
+    fake["torch_utils.persistence"]._reconstruct_persistent_obj = _reconstruct_persistent_obj
+    _reconstruct_persistent_obj.__module__, _reconstruct_persistent_obj.__qualname__ = "torch_utils.persistence", "_reconstruct_persistent_obj"
+    fake["dnnlib.util"].EasyDict = EasyDict
+    EasyDict.__module__, EasyDict.__qualname__ = "dnnlib.util", "EasyDict"
+    saved = {k: sys.modules.get(k) for k in fake}
+    sys.modules.update(fake)
+    try:
+        with open(path, "wb") as f:
+            pickle.dump(EasyDict(encoder=None, dataset_kwargs=dict(path="x"), loss_fn=None, ema=top), f)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def test_driver_accepts_snapshot_paths(tmp_path):
+    """generate_images_nvs(net="network-snapshot-*.pkl") (generate_images.py:164-169) through vivid_amd.snapshot: the images equal
+    those of the module built directly from the same (fp16-rounded) weights."""
+    import vivid_amd
+    from vivid_amd.generate import generate_images_nvs
+    cfg = CASES["tiny_dual"]["cfg"]
+    sd = vivid_amd.synth_state_dict(cfg, seed=3)
+    path = str(tmp_path / "network-snapshot-0000001.pkl")
+    _write_snapshot_like(path, cfg, sd)
+    direct = vivid_amd.NVPrecond.from_config(cfg)
+    direct.load_state_dict({k: v.to(torch.float16).to(torch.float32) for k, v in sd.items()})
+    direct = direct.cuda()
+    a = list(generate_images_nvs(path, seeds=[16, 17], max_batch_size=2, data=_data(4, 16, 5), num_steps=2))
+    b = list(generate_images_nvs(direct, seeds=[16, 17], max_batch_size=2, data=_data(4, 16, 5), num_steps=2))
+    assert a[0].images.shape == (2, 3, 16, 16)
+    assert torch.equal(a[0].images, b[0].images)
