@@ -81,6 +81,30 @@ def test_conv_store_fp32(ctx, rows, h, w, cin, cout, taps):
     assert rel_l2(out.cpu(), _nhwc(ref)) < 2e-5
 
 
+@pytest.mark.parametrize("cout,taps", [(64, 9), (48, 9), (64, 1)])
+def test_conv_glds_slim_tile_large_m(ctx, cout, taps):
+    """Cout <= 64 at >= 512 pixel tiles of 512 takes the 512x64 tile shape (full-resolution layers of the SR net)."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(cout + taps)
+    rows, h, w, cin = 1, 512, 512, 32
+    x = torch.randn(rows, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, *([3, 3] if taps == 9 else [1, 1]), generator=g)
+    ref = R.mp_conv(x, wgt, gain=1.0)
+    M = rows * h * w
+    xd = _nhwc(x).cuda()
+    xs8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), taps, split=2)
+    out = torch.empty(M, cout, device="cuda")
+    ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                  scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0,
+                                  prec=1, kernel=1, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 2e-5
+
+
 MODES = [(0, 0), (1, 0), (1, 1)]     # (prec, kernel): fp32 tile128 | bf16x3 tile128 | bf16x3 glds256
 
 

@@ -376,7 +376,10 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
     // 512x128 tiles (same 128x64 wave tile as the wide config) when only the narrow N fits and M is large
     const bool tall = !wide && ((M + 511) / 512) * ((a.cout + 127) / 128) >= 512;
-    const int BN = wide ? 256 : 128, BMt = tall ? 512 : 256;
+    // 512x64 tiles (8 waves of 64x64) for Cout <= 64 at large M - the full-resolution layers of the super-resolution net,
+    // where a 128-wide tile would spend half of its MFMAs and B traffic on zero columns
+    const bool slim = a.cout <= 64 && (M + 511) / 512 >= 512;
+    const int BN = wide ? 256 : slim ? 64 : 128, BMt = (tall || slim) ? 512 : 256;
     const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
     k.NT = (int)NT;
@@ -393,14 +396,15 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
     static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
-    const int cfg = tall ? 2 : wide ? 1 : 0;
+    const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
     const bool use16 = m16;
     if (a.epi == VH_EPI_QKV && !use16) return vh_fail(VH_EINVAL, "vh_conv: the QKV epilogue exists only in the 16x16x32-MFMA kernels (unset VIVID_CONV_MFMA)");
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, use16, grid](hipStream_t s) -> int {
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, M16_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, M16_>), dim3(grid), dim3(512), 0, s, k)
 #define VH_LAUNCH_CFG(T, M16_)                                  \
         do {                                                    \
-            if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, M16_);       \
+            if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, M16_);       \
+            else if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, M16_);  \
             else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, M16_);  \
             else VH_LAUNCH(T, 4, 2, 2, 2, M16_);                \
         } while (0)
