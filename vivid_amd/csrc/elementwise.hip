@@ -131,18 +131,22 @@ __global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long np
     }
 }
 
-// Register-resident form for c <= 512: a wave takes PPW pixels, issues all of their loads up front (the one-pixel-per-wave
-// form above has one dependent load -> reduce -> store chain per wave: latency-bound) and reads every value once.
-template <int NV, bool POOL, int PPW>
+// Register-resident form for c <= 512: a wave takes PPW groups of 64/LPP pixels (LPP lanes per pixel: 16 or 32 for
+// c <= 64 / 128 so that no lane idles), issues all of their loads up front (the one-pixel-per-wave form above has one
+// dependent load -> reduce -> store chain per wave: latency-bound) and reads every value once.
+template <int NV, int LPP, bool POOL, int PPW>
 __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long long npix) {
-    const long long p0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW;
+    constexpr int PW = 64 / LPP;                                   // pixels side by side in a wave
+    const long long p0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (PPW * PW);
     if (p0 >= npix) return;
     const int lane = threadIdx.x & 63;
+    const int li = lane & (LPP - 1), sub = lane / LPP;
     const int c4 = a.c >> 2;
     float4 v[PPW][NV];
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-        const long long p = p0 + q < npix ? p0 + q : npix - 1;
+        const long long pq = p0 + q * PW + sub;
+        const long long p = pq < npix ? pq : npix - 1;
         const float4* s0;
         size_t o1 = 0, o2 = 0, o3 = 0;
         if (POOL) {
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
         }
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
-            const int i = lane + 64 * n;
+            const int i = li + LPP * n;
             float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < c4) {
                 t = s0[i];
@@ -173,13 +177,14 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
     }
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
-        const long long p = p0 + q;
+        const long long p = p0 + q * PW + sub;
         float scale = 1.f;
         if (a.norm) {
             float ss = 0.f;
 #pragma unroll
             for (int n = 0; n < NV; ++n) ss += v[q][n].x * v[q][n].x + v[q][n].y * v[q][n].y + v[q][n].z * v[q][n].z + v[q][n].w * v[q][n].w;
-            ss = wave_sum(ss);
+#pragma unroll
+            for (int o = LPP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
             scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
         }
         if (p >= npix) continue;
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
         unsigned short* s8 = a.out_s8 ? static_cast<unsigned short*>(a.out_s8) + (size_t)p * a.c * 2 : nullptr;
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
-            const int i = lane + 64 * n;
+            const int i = li + LPP * n;
             if (i >= c4) continue;
             float4 t = v[q][n];
             t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
@@ -560,15 +565,18 @@ extern "C" int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* p) {
     return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * ((a.pool ? 5.0 : 2.0) + (a.out_s8 ? 1.0 : 0.0)), [a, npix](hipStream_t s) -> int {
         const int c4 = a.c >> 2;
         const bool inplace_pool = a.pool && a.in == a.out;       // (never used by the engine; the register form reads neighbours late)
-        if (c4 <= 64 && !inplace_pool) {
-            if (a.pool) hipLaunchKernelGGL((pixnorm_reg_k<1, true, 2>), dim3(blocks_for(npix, 8)), dim3(256), 0, s, a, npix);
-            else hipLaunchKernelGGL((pixnorm_reg_k<1, false, 4>), dim3(blocks_for(npix, 16)), dim3(256), 0, s, a, npix);
-        } else if (c4 <= 128 && !inplace_pool) {
-            if (a.pool) hipLaunchKernelGGL((pixnorm_reg_k<2, true, 2>), dim3(blocks_for(npix, 8)), dim3(256), 0, s, a, npix);
-            else hipLaunchKernelGGL((pixnorm_reg_k<2, false, 4>), dim3(blocks_for(npix, 16)), dim3(256), 0, s, a, npix);
-        } else {
-            hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
-        }
+#define VH_PIX(NV_, LPP_)                                                                                                         \
+        do {                                                                                                                      \
+            constexpr int PW = 64 / LPP_;                                                                                         \
+            if (a.pool) hipLaunchKernelGGL((pixnorm_reg_k<NV_, LPP_, true, 2>), dim3(blocks_for(npix, 8 * PW)), dim3(256), 0, s, a, npix);  \
+            else hipLaunchKernelGGL((pixnorm_reg_k<NV_, LPP_, false, 4>), dim3(blocks_for(npix, 16 * PW)), dim3(256), 0, s, a, npix);        \
+        } while (0)
+        if (inplace_pool || c4 > 128) hipLaunchKernelGGL(pixnorm_k, dim3(blocks_for(npix, 4)), dim3(256), 0, s, a, npix);
+        else if (c4 <= 16) VH_PIX(1, 16);
+        else if (c4 <= 32) VH_PIX(1, 32);
+        else if (c4 <= 64) VH_PIX(1, 64);
+        else VH_PIX(2, 64);
+#undef VH_PIX
         return vh_check_launch("pixnorm_k");
     });
 }
