@@ -678,7 +678,7 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     // slower: every workgroup stages its own copy of the K/V stream).
     const int nw = a.s > 128 ? 8 : 4;
     static const bool use_pipe = !(getenv("VIVID_ATTN_PIPE") && atoi(getenv("VIVID_ATTN_PIPE")) == 0);
-    const bool pipe = use_pipe && nw == 8 && a.kl > KT && a.d == 64;   // (the D=32 instantiation spills its accumulators)
+    const bool pipe = use_pipe && nw == 8 && a.kl > KT;
     VH_REQUIRE(a.logit_bound >= 0.f, "vh_attention_x3: negative logit_bound");
     static const bool nomax_on = !(getenv("VIVID_ATTN_NOMAX") && atoi(getenv("VIVID_ATTN_NOMAX")) == 0);
     const bool nomax = nomax_on && a.logit_bound > 0.f && a.logit_bound <= 64.f;
@@ -687,8 +687,10 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     const double flops = 4.0 * bhd * a.s * a.kl * a.d;
     const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);
     return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, nomax, grid](hipStream_t s) -> int {
-        if (pipe && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64, true>), grid, dim3(512), 0, s, k);
-        else if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
+        if (pipe && d == 64 && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64, true>), grid, dim3(512), 0, s, k);
+        else if (pipe && d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
+        else if (pipe && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32, true>), grid, dim3(512), 0, s, k);
+        else if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32>), grid, dim3(512), 0, s, k);
         else if (d == 64 && nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 8>), grid, dim3(512), 0, s, k);
         else if (d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 4>), grid, dim3(256), 0, s, k);
         else if (nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<32, 8>), grid, dim3(512), 0, s, k);
