@@ -60,3 +60,23 @@ def test_argument_validation_without_gpu():
         ctx.plan_begin()
     plan = ctx.plan_end()
     assert plan.num_ops == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """No silent fallback: without libvivid_hip.so the loader raises and so does the product path that needs it."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libvivid_hip.so"))
+    with pytest.raises(_lib.VividHipError, match="not built"):
+        _lib.lib()
+
+
+def test_cpu_tensors_are_refused_by_the_network():
+    """The denoiser has no CPU implementation in the product: CPU inputs raise instead of taking another path."""
+    import torch
+    import vivid_amd
+    from tests.golden.cases import CASES
+    cfg = CASES["tiny_dual"]["cfg"]
+    net = vivid_amd.NVPrecond.from_config(cfg)
+    x = torch.zeros(2, 3, cfg.img_resolution, cfg.img_resolution)
+    with pytest.raises(RuntimeError):
+        net(x, x, torch.ones(2), torch.zeros(2, 20))
