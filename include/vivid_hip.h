@@ -316,13 +316,21 @@ int vh_add_depth(vh_ctx* ctx, const vh_add_depth_args* a);
  * torchvision.transforms.functional.resize on tensors = F.interpolate(mode="bilinear", align_corners=False,
  * antialias=...): source coordinate (i+0.5)*scale-0.5; with antialias and scale > 1 the triangle filter is widened
  * to `scale` (aten upsample_bilinear2d_aa); weights are normalised per output pixel. */
+enum { VH_RESIZE_BILINEAR = 0, VH_RESIZE_BICUBIC = 1 };
 typedef struct {
     const float* in; float* out;
     int planes;            /* rows * channels */
     int hin, win, hout, wout;
-    int antialias;
+    int antialias;         /* bilinear, align_corners == 0 only */
+    int mode;              /* VH_RESIZE_*; bicubic = cubic convolution with A = -0.75, border-clamped taps (aten upsample_bicubic2d) */
+    int align_corners;     /* 1: source coordinate i*(in-1)/(out-1) */
+    const float* ch_scale; const float* ch_bias; int channels;   /* optional per-channel affine on the result: y*ch_scale[c] + ch_bias[c],
+                                                                    c = plane % channels (the /255 and ImageNet normalisation of depth_prepare) */
 } vh_resize_args;
-int vh_resize_bilinear(vh_ctx* ctx, const vh_resize_args* a);
+int vh_resize_bilinear(vh_ctx* ctx, const vh_resize_args* a);   /* mode must be VH_RESIZE_BILINEAR */
+/* General form: also the depth front end of configuration 5 - depth_prepare (bicubic to 518, align_corners, training/utils.py:107-115)
+ * and the depth map's way back to image size (bilinear, align_corners, :125).  The depth model between them is external. */
+int vh_resize(vh_ctx* ctx, const vh_resize_args* a);
 
 /* ---- K16: sampler update (generate_images.py:93-94,108-109) ---------------
  * d = (x - D)/t_hat;  Euler: x_next = x + (t_next - t_hat) * d           (d_out written)

@@ -176,3 +176,44 @@ def test_driver_accepts_snapshot_paths(tmp_path):
     b = list(generate_images_nvs(direct, seeds=[16, 17], max_batch_size=2, data=_data(4, 16, 5), num_steps=2))
     assert a[0].images.shape == (2, 3, 16, 16)
     assert torch.equal(a[0].images, b[0].images)
+
+
+@pytest.mark.parametrize("mode,hin,hout", [("bicubic", 64, 518), ("bicubic", 37, 20), ("bilinear", 518, 64), ("bilinear", 9, 33)])
+def test_resize_align_corners_modes_match_torch(mode, hin, hout):
+    from vivid_amd.encoders import _resize
+    g = torch.Generator().manual_seed(hin + hout)
+    x = torch.randn(2, 3, hin, hin + 3, generator=g)
+    ref = torch.nn.functional.interpolate(x, size=(hout, hout + 1), mode=mode, align_corners=True)
+    got = _resize(x.cuda(), (hout, hout + 1), mode, True)
+    assert rel_l2(got.cpu(), ref) < 2e-6
+
+
+def test_depth_front_end_matches_reference_formulas():
+    """depth_prepare / get_depth / add_depth of training/utils.py:107-139 with a stand-in depth network (the real one is external).
+    kornia's resize is F.interpolate with the same arguments (kornia itself is not installed: SURVEY 8(c))."""
+    import vivid_amd
+    g = torch.Generator().manual_seed(11)
+    img = torch.randint(0, 256, (2, 3, 64, 64), generator=g).float()
+    src = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    want_in = ((torch.nn.functional.interpolate(img / 255, size=(518, 518), mode="bicubic", align_corners=True) - mean) / std).to(torch.float16)
+    got_in = vivid_amd.depth_prepare(img.cuda())
+    assert got_in.dtype == torch.float16 and got_in.shape == (2, 3, 518, 518)
+    assert rel_l2(got_in.float().cpu(), want_in.float()) < 1e-3          # fp16 output: one rounding apart at most
+
+    def fake_model(x):                                                   # [N,3,518,518] fp16 -> positive "depth" [N,518,518]
+        return x.float().abs().mean(dim=1) + 0.5
+
+    want_d = torch.nn.functional.interpolate(fake_model(want_in)[:, None], (64, 64), mode="bilinear", align_corners=True)
+    got_d = vivid_amd.get_depth(fake_model, img.cuda())
+    assert got_d.shape == (2, 1, 64, 64) and rel_l2(got_d.cpu(), want_d) < 1e-3
+    for inv in (False, True):
+        d = want_d
+        if inv:
+            d = 1 / d
+            d = d / d.amax((1, 2, 3), keepdim=True)
+            d = (d - 0.4947) / 0.2294
+        want = torch.cat([src, d], dim=1)
+        got = vivid_amd.add_depth_from_model(fake_model, img.cuda(), src.cuda(), inv)
+        assert got.shape == (2, 4, 64, 64) and rel_l2(got.cpu(), want) < 2e-3

@@ -114,7 +114,8 @@ class AddDepthArgs(C.Structure):
 
 class ResizeArgs(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("planes", C.c_int), ("hin", C.c_int), ("win", C.c_int),
-                ("hout", C.c_int), ("wout", C.c_int), ("antialias", C.c_int)]
+                ("hout", C.c_int), ("wout", C.c_int), ("antialias", C.c_int), ("mode", C.c_int), ("align_corners", C.c_int),
+                ("ch_scale", C.c_void_p), ("ch_bias", C.c_void_p), ("channels", C.c_int)]
 
 
 class SamplerStepArgs(C.Structure):
@@ -130,7 +131,7 @@ OPS = {
     "vh_qkv_split_x3": QkvSplitArgs, "vh_attention_x3": AttentionArgs,
     "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
     "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs, "vh_codec": CodecArgs, "vh_add_depth": AddDepthArgs,
-    "vh_resize_bilinear": ResizeArgs,
+    "vh_resize_bilinear": ResizeArgs, "vh_resize": ResizeArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
 CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",

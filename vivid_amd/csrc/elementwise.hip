@@ -483,6 +483,16 @@ __global__ __launch_bounds__(256) void add_depth_k(vh_add_depth_args a) {
 // ---------------------------------------------------------------- bilinear resize (optionally anti-aliased)
 __device__ __forceinline__ float tri(float x) { x = fabsf(x); return x < 1.f ? 1.f - x : 0.f; }
 
+// cubic convolution weights of the 4 taps at offsets -1, 0, 1, 2 for fraction t (A = -0.75: aten's get_cubic_upsample_coefficients)
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x1 = t, x2 = 1.f - t, x3 = 2.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
 __global__ __launch_bounds__(256) void resize_k(vh_resize_args a, long long total) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -493,8 +503,27 @@ __global__ __launch_bounds__(256) void resize_k(vh_resize_args a, long long tota
     const float sy = (float)a.hin / a.hout, sx = (float)a.win / a.wout;
     const float* src = a.in + (size_t)pl * a.hin * a.win;
     float acc = 0.f;
-    if (!a.antialias) {
-        float fy = (yo + 0.5f) * sy - 0.5f, fx = (xo + 0.5f) * sx - 0.5f;
+    const float ay = a.hout > 1 ? (float)(a.hin - 1) / (a.hout - 1) : 0.f, ax = a.wout > 1 ? (float)(a.win - 1) / (a.wout - 1) : 0.f;
+    if (a.mode == VH_RESIZE_BICUBIC) {
+        // aten upsample_bicubic2d: 4x4 taps around floor(coordinate), indices clamped to the border, A = -0.75
+        const float fy = a.align_corners ? yo * ay : (yo + 0.5f) * sy - 0.5f;
+        const float fx = a.align_corners ? xo * ax : (xo + 0.5f) * sx - 0.5f;
+        const float fy0 = floorf(fy), fx0 = floorf(fx);
+        const float ty = fy - fy0, tx = fx - fx0;
+        const int iy = (int)fy0, ix = (int)fx0;
+        float wy[4], wx[4];
+        cubic_coeffs(ty, wy);
+        cubic_coeffs(tx, wx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = min(max(iy - 1 + j, 0), a.hin - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) row += wx[i2] * src[y * a.win + min(max(ix - 1 + i2, 0), a.win - 1)];
+            acc += wy[j] * row;
+        }
+    } else if (!a.antialias) {
+        float fy = a.align_corners ? yo * ay : (yo + 0.5f) * sy - 0.5f, fx = a.align_corners ? xo * ax : (xo + 0.5f) * sx - 0.5f;
         fy = fmaxf(fy, 0.f); fx = fmaxf(fx, 0.f);
         const int y0 = min((int)fy, a.hin - 1), x0 = min((int)fx, a.win - 1);
         const int y1 = min(y0 + 1, a.hin - 1), x1 = min(x0 + 1, a.win - 1);
@@ -516,6 +545,10 @@ __global__ __launch_bounds__(256) void resize_k(vh_resize_args a, long long tota
             for (int x = xmin; x < xmax; ++x) row += tri((x - cx + 0.5f) / supx) / wx_sum * src[y * a.win + x];
             acc += wy * row;
         }
+    }
+    if (a.ch_scale) {
+        const int c = (int)(pl % a.channels);
+        acc = acc * a.ch_scale[c] + a.ch_bias[c];
     }
     a.out[i] = acc;
 }
@@ -691,16 +724,24 @@ extern "C" int vh_add_depth(vh_ctx* ctx, const vh_add_depth_args* p) {
     });
 }
 
-extern "C" int vh_resize_bilinear(vh_ctx* ctx, const vh_resize_args* p) {
-    if (!p) return vh_fail(VH_EINVAL, "vh_resize_bilinear: null args");
+extern "C" int vh_resize(vh_ctx* ctx, const vh_resize_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_resize: null args");
     const vh_resize_args a = *p;
-    VH_REQUIRE(a.in && a.out, "vh_resize_bilinear: null tensor");
-    VH_REQUIRE(a.planes > 0 && a.hin > 0 && a.win > 0 && a.hout > 0 && a.wout > 0, "vh_resize_bilinear: bad geometry");
+    VH_REQUIRE(a.in && a.out, "vh_resize: null tensor");
+    VH_REQUIRE(a.planes > 0 && a.hin > 0 && a.win > 0 && a.hout > 0 && a.wout > 0, "vh_resize: bad geometry");
+    VH_REQUIRE(a.mode == VH_RESIZE_BILINEAR || a.mode == VH_RESIZE_BICUBIC, "vh_resize: bad mode %d", a.mode);
+    VH_REQUIRE(!a.antialias || (a.mode == VH_RESIZE_BILINEAR && !a.align_corners), "vh_resize: antialias exists for bilinear, align_corners = 0 only");
+    VH_REQUIRE(!a.ch_scale || (a.ch_bias && a.channels > 0 && a.planes % a.channels == 0), "vh_resize: per-channel affine needs ch_bias and channels dividing planes");
     const long long total = (long long)a.planes * a.hout * a.wout;
     return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 4.0 * ((double)total + (double)a.planes * a.hin * a.win), [a, total](hipStream_t s) -> int {
         hipLaunchKernelGGL(resize_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
         return vh_check_launch("resize_k");
     });
+}
+
+extern "C" int vh_resize_bilinear(vh_ctx* ctx, const vh_resize_args* p) {
+    if (p && p->mode != VH_RESIZE_BILINEAR) return vh_fail(VH_EINVAL, "vh_resize_bilinear: mode must be VH_RESIZE_BILINEAR (use vh_resize)");
+    return vh_resize(ctx, p);
 }
 
 extern "C" int vh_sampler_step(vh_ctx* ctx, const vh_sampler_step_args* p) {

@@ -59,3 +59,53 @@ def add_depth(depth: torch.Tensor, src: torch.Tensor, inv_norm: bool) -> torch.T
         _context(src.device).call("vh_add_depth", L.AddDepthArgs(src=src.data_ptr(), c=Cc, depth=depth.data_ptr(), rows=N, h=H, w=W,
                                                                  inv_norm=1 if inv_norm else 0, out=out.data_ptr()))
     return out
+
+
+def _resize(x: torch.Tensor, size, mode: str, align_corners: bool, ch_scale=None, ch_bias=None) -> torch.Tensor:
+    if x.device.type != "cuda":
+        raise RuntimeError("vivid_amd resize kernels run on the GPU")
+    x = x.to(torch.float32).contiguous()
+    N, Cc, H, W = x.shape
+    ho, wo = (size, size) if isinstance(size, int) else tuple(size)
+    out = torch.empty(N, Cc, ho, wo, dtype=torch.float32, device=x.device)
+    sc = bi = None
+    if ch_scale is not None:
+        sc = torch.as_tensor(ch_scale, dtype=torch.float32, device=x.device).contiguous()
+        bi = torch.as_tensor(ch_bias, dtype=torch.float32, device=x.device).contiguous()
+        assert sc.numel() == Cc and bi.numel() == Cc
+    with torch.cuda.device(x.device):
+        _context(x.device).call("vh_resize", L.ResizeArgs(
+            inp=x.data_ptr(), out=out.data_ptr(), planes=N * Cc, hin=H, win=W, hout=ho, wout=wo, antialias=0,
+            mode={"bilinear": 0, "bicubic": 1}[mode], align_corners=1 if align_corners else 0,
+            ch_scale=sc.data_ptr() if sc is not None else None, ch_bias=bi.data_ptr() if bi is not None else None, channels=Cc))
+    return out
+
+
+_IMAGENET_MEAN = (0.485, 0.456, 0.406)
+_IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def depth_prepare(x: torch.Tensor) -> torch.Tensor:
+    """Image in [0,255] -> the input of a DepthAnythingV2 model (training/utils.py:107-115): /255, bicubic resize to 518
+    with align_corners (kornia.geometry.transform.resize = F.interpolate of the same arguments), ImageNet normalisation,
+    fp16.  One kernel: the affine (y/255 - mean)/std is applied to the interpolated value."""
+    assert x.shape[1] == 3, "depth_prepare expects RGB"
+    H, W = x.shape[-2:]
+    size = (518, 518) if H == W else ((518, int(518 * W / H)) if H < W else (int(518 * H / W), 518))   # kornia side='short'
+    sc = [1.0 / (255.0 * s) for s in _IMAGENET_STD]
+    bi = [-m / s for m, s in zip(_IMAGENET_MEAN, _IMAGENET_STD)]
+    return _resize(x, size, "bicubic", True, sc, bi).to(torch.float16)
+
+
+def get_depth(depth_model, image: torch.Tensor, shape=None) -> torch.Tensor:
+    """depth_model(depth_prepare(image)) resized to `shape` (bilinear, align_corners) as [N,1,h,w]   (training/utils.py:118-126).
+    `depth_model` is any callable returning [N, h', w'] (the monocular depth network itself is external)."""
+    shape = tuple(image.shape[-2:]) if shape is None else tuple(shape[-2:])
+    with torch.no_grad():
+        depth = depth_model(depth_prepare(image)).to(torch.float32)[:, None]
+        return _resize(depth, shape, "bilinear", True)
+
+
+def add_depth_from_model(depth_model, image: torch.Tensor, src: torch.Tensor, inv_norm: bool) -> torch.Tensor:
+    """The reference's add_depth(depth_model, image, src, inv_norm) (training/utils.py:129-139)."""
+    return add_depth(get_depth(depth_model, image, src.shape[-2:]), src, inv_norm)
