@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         pbase[j] = img * Hs * Ws;
     }
     const float4* pa[RA];                                  // per-tap A pointers (already + unit u)
-    const float4* pb[RB];                                  // B pointers, advanced by 8 units per K-tile
+    const float4* pb[RB];                                  // B row pointers (+ unit u); the K offset is added per tile
     const float4* zp = reinterpret_cast<const float4*>(a.zeros);
     const int KU = a.k_pad >> 2;                           // 16-byte units per weight row
     bool bzero[RB];
@@ -95,9 +95,33 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     for (int j = 0; j < RB; ++j) {
         const int gn = n0 + j * 64 + rsub;
         bzero[j] = gn >= a.cout;
-        pb[j] = bzero[j] ? zp : a.wt + (size_t)gn * KU + u;
+        pb[j] = a.wt + (size_t)(bzero[j] ? 0 : gn) * KU + u;
     }
 
+    // chunk-major K order (a.korder): the tap changes every K-tile, so instead of re-deriving coordinates the kernel keeps,
+    // per slot, the pointer of the centre pixel and a 9-bit mask of the taps that fall inside the image; a tap's pointer is
+    // then centre + (dy*W + dx)*C (one scalar offset) or the zero page.  Not for `up` (the source offset is not uniform).
+    const float4* pc[RA];
+    unsigned pmask[RA];
+    if (TAPS == 9 && a.korder) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            unsigned m = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yy = py[j] + tp / 3 - 1, xx = px[j] + tp % 3 - 1;
+                if (pv[j] && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w) m |= 1u << tp;
+            }
+            pmask[j] = m;
+            pc[j] = reinterpret_cast<const float4*>(a.src0 + (size_t)(pbase[j] + py[j] * a.w + px[j]) * a.c0) + u;
+        }
+    }
+    auto setup_tap_fast = [&](int tap) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const long long off = (long long)(dy * a.w + dx) * (a.c0 >> 2);       // in 16-byte units, wave-uniform
+#pragma unroll
+        for (int j = 0; j < RA; ++j) pa[j] = ((pmask[j] >> tap) & 1u) ? pc[j] + off : zp;
+    };
     auto setup_tap = [&](int tap) {
         int dy = 0, dx = 0;
         if (TAPS == 9) {
@@ -115,16 +139,15 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     };
 
     // issue the DMA of one K-tile (cc = channel offset inside the tap) into LDS stage `st`
-    auto issue = [&](int st, int cc) {
+    auto issue = [&](int st, int tap, int cc) {
         const int cu = cc >> 2;                            // channel offset in 16-byte units
+        const int bu = (tap * a.cin_pad + cc) >> 2;        // K offset of the weight tile, same units
 #pragma unroll
         for (int j = 0; j < RA; ++j)
             glds16(pa[j] + cu, &sA[st][j * 512 + w * 64]);
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            glds16(pb[j], &sB[st][j * 512 + w * 64]);
-            if (!bzero[j]) pb[j] += 8;
-        }
+        for (int j = 0; j < RB; ++j)
+            glds16(bzero[j] ? zp : pb[j] + bu, &sB[st][j * 512 + w * 64]);
     };
 
     f32x16 acc[M16 ? 1 : MI][M16 ? 1 : NI];
@@ -210,24 +233,33 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     // ---- main loop: DMA of tile t+1 in flight during the MFMAs of tile t; one barrier per tile ------------
     const int KTall = a.k_pad / BK;
     const int kt0 = (int)((long long)KTall * ks / a.ksplit), KT = (int)((long long)KTall * (ks + 1) / a.ksplit) - kt0;
-    int tap = (kt0 * BK) / a.cin_pad, cc = kt0 * BK - tap * a.cin_pad;
-#pragma unroll
-    for (int j = 0; j < RB; ++j)
-        if (!bzero[j]) pb[j] += (size_t)kt0 * 8;
-    setup_tap(tap);
-    issue(0, cc);
+    // K-tile order.  Tap-major (all channel chunks of tap 0, then tap 1, ...) derives the pixel pointers once per tap, but a
+    // pixel's 128-byte line comes back for the next tap only after a whole channel sweep of every tile on the XCD:
+    // at the full-resolution levels that is more than the 4 MB L2 and each tap re-fetches its input from beyond it (~5x the
+    // algorithmic bytes, profiles/).  Chunk-major (the 9 taps of channels 0-31, then of 32-63, ...) re-uses a line within
+    // 9 consecutive K-tiles.
+    const bool chunk_major = TAPS == 9 && a.korder;
+    int tap, cc;
+    if (chunk_major) { cc = (kt0 / 9) * BK; tap = kt0 - (kt0 / 9) * 9; setup_tap_fast(tap); }
+    else { tap = (kt0 * BK) / a.cin_pad; cc = kt0 * BK - tap * a.cin_pad; setup_tap(tap); }
+    issue(0, tap, cc);
     wait_dma();
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const int st = kt & 1;
         if (kt + 1 < KT) {
-            cc += BK;
-            if (cc >= a.cin_pad) {
-                cc = 0;
-                ++tap;
-                setup_tap(tap);
+            if (chunk_major) {
+                if (++tap == 9) { tap = 0; cc += BK; }
+                setup_tap_fast(tap);
+            } else {
+                cc += BK;
+                if (cc >= a.cin_pad) {
+                    cc = 0;
+                    ++tap;
+                    setup_tap(tap);
+                }
             }
-            issue(st ^ 1, cc);
+            issue(st ^ 1, tap, cc);
         }
         compute(st);
         wait_dma();                                        // this wave's DMA of tile kt+1 has landed ...
@@ -393,6 +425,12 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     }
     k.ksplit = ksplit;
     k.scratch = a.scratch;
+    // chunk-major K order when the input does not stay in the 256 MB Infinity Cache either: with tap-major order each tap's
+    // re-read then comes from HBM.  Measured: +7..10 % at 256x256 (0.5-1 GB inputs), +3..4 % at 128x128 (0.27-0.54 GB),
+    // +1.6 % at 0.2 GB, -2 % at 67 MB (the per-K-tile pointer selection costs VALU and buys nothing there).
+    static const int korder_env = getenv("VIVID_CONV_KORDER") ? atoi(getenv("VIVID_CONV_KORDER")) : -1;
+    const bool big_input = (double)M * a.cin_pad * 4.0 > 1.5e8;
+    k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : (big_input ? 1 : 0)) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
     static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
