@@ -80,7 +80,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvK& a, const f32x16 
 // 4 consecutive output channels of one pixel: residual / cvec loads and the fp32 / S8 stores are 16-byte (8-byte for
 // the bf16 halves) accesses, 8 lanes per 128-byte line, instead of 4-byte accesses - a quarter of the memory
 // instructions (the accumulator-layout epilogue is store-issue bound).  `patch`: 32 x 36 floats owned by this wave.
-__device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane);
+struct EpiAux;
+__device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane, const EpiAux* aux);
 
 __device__ __forceinline__ void conv_epilogue_tile_lds(const ConvK& a, const f32x16 accv, int row0, int col0,
                                                         float* patch, int lane) {
@@ -89,13 +90,14 @@ __device__ __forceinline__ void conv_epilogue_tile_lds(const ConvK& a, const f32
 #pragma unroll
     for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * hh) * LD + lr] = accv[r];
     // (same wave wrote and reads: the compiler orders the ds_read behind the ds_writes with lgkmcnt)
-    conv_epilogue_patch(a, row0, col0, patch, lane);
+    conv_epilogue_patch(a, row0, col0, patch, lane, nullptr);
 }
 
 // Same for a 32x32 block held as 2x2 accumulator tiles of v_mfma_f32_16x16x32 (C/D map: column = lane&15,
 // row = 4*(lane>>4) + reg).
 __device__ __forceinline__ void conv_epilogue_tiles16_lds(const ConvK& a, const f32x4 t00, const f32x4 t01, const f32x4 t10,
-                                                           const f32x4 t11, int row0, int col0, float* patch, int lane) {
+                                                           const f32x4 t11, int row0, int col0, float* patch, int lane,
+                                                           const EpiAux* aux = nullptr) {
     constexpr int LD = 36;
     const int c = lane & 15, rb = (lane >> 4) * 4;
 #pragma unroll
@@ -105,16 +107,29 @@ __device__ __forceinline__ void conv_epilogue_tiles16_lds(const ConvK& a, const 
         patch[(16 + rb + r) * LD + c] = t10[r];
         patch[(16 + rb + r) * LD + 16 + c] = t11[r];
     }
-    conv_epilogue_patch(a, row0, col0, patch, lane);
+    conv_epilogue_patch(a, row0, col0, patch, lane, aux);
 }
 
 // Read-out of a 32 x 36-float patch: every lane handles 4 consecutive output channels of one pixel.
 // Epilogue of 4 consecutive output channels gn..gn+3 of pixel gm (y = raw sums): shared by the LDS patch read-out
 // and by the split-K reducer.
-__device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int gn, float (&y)[4]) {
+// `aux`: the residual (MPSUM) or cvec (SCALE_SILU) values of these 4 channels when the caller fetched them ahead
+// (conv_epilogue_prefetch), else nullptr.
+__device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int gn, float (&y)[4], const float4* aux = nullptr) {
     if (gm >= a.M || gn >= a.cout) return;
     const bool full = gn + 3 < a.cout;
-    if (a.epi == VH_EPI_SCALE_SILU) {
+    if (aux && a.epi == VH_EPI_SCALE_SILU) {
+        const float c[4] = {aux->x, aux->y, aux->z, aux->w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = mp_silu_dev(y[j] * c[j]);
+    } else if (aux && a.epi == VH_EPI_MPSUM) {
+        const float rv[4] = {aux->x, aux->y, aux->z, aux->w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j] = rv[j] * a.ta + y[j] * a.tb;
+            if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
+        }
+    } else if (a.epi == VH_EPI_SCALE_SILU) {
         const int img = gm / a.HW;
         const float* cp = a.cvec + (size_t)img * a.cvec_ld + gn;
 #pragma unroll
@@ -167,16 +182,49 @@ __device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int g
     }
 }
 
-__device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane) {
+// The residual / cvec values the read-out of block (row0, col0) will need, fetched AHEAD of it: the epilogue walks its 32x32
+// blocks one after the other, each ending in stores the compiler may not move the next block's loads across, so without
+// this every block waits out one full global-load latency.  Valid only when `ok` (aligned, whole vectors in range).
+struct EpiAux { float4 v[4]; bool ok; };
+__device__ __forceinline__ EpiAux conv_epilogue_prefetch(const ConvK& a, int row0, int col0, int lane) {
+    EpiAux x;
+    const int cg = lane & 7, rsub = lane >> 3;
+    const int gn = col0 + 4 * cg;
+    x.ok = (a.epi == VH_EPI_MPSUM || a.epi == VH_EPI_SCALE_SILU) && (a.cout & 3) == 0 && (a.epi != VH_EPI_SCALE_SILU || (a.cvec_ld & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gm = row0 + rsub + 8 * i;
+        if (!x.ok || gm >= a.M || gn + 3 >= a.cout) continue;
+        if (a.epi == VH_EPI_MPSUM) {
+            size_t rrow = (size_t)gm;
+            if (a.res_up) {
+                const int Hr = a.h >> 1, Wr = a.w >> 1;
+                const int img = gm / a.HW;
+                const int rem = gm - img * a.HW;
+                const int yy = rem / a.w, xx = rem - yy * a.w;
+                rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
+            }
+            x.v[i] = *reinterpret_cast<const float4*>(a.res + rrow * a.cout + gn);
+        } else {
+            x.v[i] = *reinterpret_cast<const float4*>(a.cvec + (size_t)(gm / a.HW) * a.cvec_ld + gn);
+        }
+    }
+    return x;
+}
+
+__device__ __forceinline__ void conv_epilogue_patch(const ConvK& a, int row0, int col0, const float* patch, int lane,
+                                                     const EpiAux* aux = nullptr) {
     constexpr int LD = 36;
     const int cg = lane & 7, rsub = lane >> 3;
     const int gn = col0 + 4 * cg;
+    const bool use_aux = aux && aux->ok && gn + 3 < a.cout;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int rl = rsub + 8 * i;
         const float4 v = *reinterpret_cast<const float4*>(&patch[rl * LD + 4 * cg]);
         float y[4] = {v.x, v.y, v.z, v.w};
-        conv_epilogue_vec4(a, row0 + rl, gn, y);
+        conv_epilogue_vec4(a, row0 + rl, gn, y, use_aux ? &aux->v[i] : nullptr);
     }
 }
 

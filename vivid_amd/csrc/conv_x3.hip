@@ -366,15 +366,26 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         e.out = a.scratch + (size_t)ks * a.M * a.cout;
         e.out_s8 = nullptr;
     }
+    if constexpr (M16) {
+        // block b's residual / cvec values are requested while block b-1 is written out (conv_epilogue_prefetch)
+        EpiAux nxt = conv_epilogue_prefetch(e, m0 + wm * MI * 32, n0 + wn * NI * 32, l);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-            if constexpr (M16)
+            for (int ni = 0; ni < NI; ++ni) {
+                const EpiAux cur = nxt;
+                const int b1 = mi * NI + ni + 1;                                   // the block after this one
+                if (b1 < MI * NI) nxt = conv_epilogue_prefetch(e, m0 + (wm * MI + b1 / NI) * 32, n0 + (wn * NI + b1 % NI) * 32, l);
                 conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
-                                          acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
-            else
+                                          acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l, &cur);
+            }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
                 conv_epilogue_tile_lds(e, acc[mi][ni], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l);
+    }
 }
 
 // split-K reducer: sums the ksplit partial-sum slabs and applies the epilogue; one thread per 4 output channels
