@@ -430,9 +430,17 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // `ksplit` workgroups per tile, partial sums through a scratch slab, epilogue in a small reducer launch
     const int KTall = a.k_pad / BK;
     int ksplit = 1;
-    if (a.scratch && MT * NT < 192 && KTall >= 16 && a.epi != VH_EPI_QKV) {
-        ksplit = (int)std::min<long long>(std::min<long long>(8, (383 + MT * NT) / (MT * NT)), KTall / 8);
-        while (ksplit > 1 && (size_t)ksplit * (size_t)M * a.cout > a.scratch_floats) --ksplit;
+    if (a.scratch && MT * NT < 256 && KTall >= 16 && a.epi != VH_EPI_QKV) {
+        // pick the slice count that minimises (rounds of 256 workgroups) x (K per slice), with a small charge per slice for the
+        // reducer's extra traffic: e.g. 128 tiles -> 2 slices (one full round), not 3 (a full and a half-empty round)
+        const int smax = (int)std::min<long long>(8, KTall / 8);
+        double best = 1e30;
+        for (int ks = 1; ks <= smax; ++ks) {
+            if ((size_t)ks * (size_t)M * a.cout > a.scratch_floats) break;
+            const double rounds = (double)((MT * NT * ks + 255) / 256);
+            const double cost = rounds / ks + 0.01 * (ks - 1);
+            if (cost < best - 1e-9) { best = cost; ksplit = ks; }
+        }
     }
     k.ksplit = ksplit;
     k.scratch = a.scratch;
