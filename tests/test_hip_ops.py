@@ -105,6 +105,62 @@ def test_conv_glds_slim_tile_large_m(ctx, cout, taps):
     assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 2e-5
 
 
+def _rand_conv_shapes():
+    """Seeded random problem shapes that walk vh_conv's dispatch: every tile shape, split-K counts, both K orders, ragged
+    M and Cout, non-square / non-power-of-two images, `up`, all three epilogues."""
+    import random
+    rnd = random.Random(1234)
+    out = []
+    for _ in range(14):
+        taps = rnd.choice([9, 9, 9, 1])
+        h, w = rnd.choice([(4, 4), (8, 6), (16, 16), (12, 20), (32, 32), (64, 48), (7, 9)])
+        rows = rnd.choice([1, 2, 3, 5])
+        cin = rnd.choice([32, 64, 96, 160, 256])
+        cout = rnd.choice([3, 24, 64, 96, 128, 200, 256, 384])
+        epi = rnd.choice([0, 1, 2])
+        up = rnd.choice([0, 0, 1]) if (h % 2 == 0 and w % 2 == 0 and taps == 9) else 0
+        out.append((rows, h, w, cin, cout, taps, epi, up))
+    out.append((2, 128, 128, 64, 128, 9, 2, 0))        # large enough for the chunk-major K order? (no: < 150 MB) - tall tiles
+    out.append((1, 64, 64, 512, 256, 9, 0, 0))         # wide tiles, 16 tiles -> split-K 8
+    return out
+
+
+@pytest.mark.parametrize("rows,h,w,cin,cout,taps,epi,up", _rand_conv_shapes())
+def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(rows * 7 + h * 3 + cin + cout + taps)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    x = torch.randn(rows, cin, hs, ws, generator=g)
+    wgt = torch.randn(cout, cin, *([3, 3] if taps == 9 else [1, 1]), generator=g)
+    xin = R.resample(x, "up") if up else x
+    y = R.mp_conv(xin, wgt, gain=1.0)
+    M = rows * h * w
+    cvec = torch.randn(rows, cout, generator=g) * 0.3 + 1
+    res = torch.randn(rows, cout, h, w, generator=g)
+    ta, tb, clip = 0.7, 0.3, 2.5
+    if epi == 1:
+        ref = R.mp_silu(y * cvec[:, :, None, None])
+    elif epi == 2:
+        ref = (res * ta + y * tb).clip(-clip, clip)
+    else:
+        ref = y
+    Ms = rows * hs * ws
+    xd = _nhwc(x).cuda()
+    xs8 = torch.empty(Ms * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=Ms, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), taps, split=2)
+    out = torch.full((M, cout), float("nan"), device="cuda")
+    cd, rd = cvec.cuda().contiguous(), _nhwc(res).cuda()
+    ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=up,
+                                  taps=taps, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                  scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0,
+                                  prec=1, kernel=1, epi=epi, cvec=cd.data_ptr() if epi == 1 else None, cvec_ld=cout if epi == 1 else 0,
+                                  res=rd.data_ptr() if epi == 2 else None, res_up=0, ta=ta, tb=tb, clip=clip if epi == 2 else 0))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
+
+
 MODES = [(0, 0), (1, 0), (1, 1)]     # (prec, kernel): fp32 tile128 | bf16x3 tile128 | bf16x3 glds256
 
 
