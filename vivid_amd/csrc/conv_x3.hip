@@ -176,7 +176,8 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     const int arow16 = (wm * MI * 32 + l15) * 8, brow16 = (wn * NI * 32 + l15) * 8;
     const int u16h = kg ^ swz16, u16l = (4 + kg) ^ swz16;
 
-    auto compute = [&](int st) {
+    // `mid`: work placed between the two A batches (the staggered waves issue their DMA there)
+    auto compute = [&](int st, auto&& mid) {
         if constexpr (M16) {
             bf16x8 bh[NI * 2], bl[NI * 2];
 #pragma unroll
@@ -201,8 +202,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
                         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
                     }
+                if (half == 0) mid();
             }
         } else {
+            mid();
 #pragma unroll
             for (int sl = 0; sl < BK / 16; ++sl) {
                 // 32x32x16 bf16: lane (row = l&31, h = l>>5) supplies k = 8h..8h+7 of the slab = chunk 2*sl + h
@@ -245,26 +248,64 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     issue(0, tap, cc);
     wait_dma();
     __syncthreads();
+    // Stagger (MI355X_MICROARCH.md "try a stagger").  s_memtime stamps of this loop (tools/_stamp_conv.py, VH_STAMP build) show that
+    // ISSUING the 8-10 DMA pieces of a K-tile costs a wave 1100-1800 cycles against 1536 of MFMA issue, and that when both waves
+    // of a SIMD do it right after the barrier the matrix pipe idles meanwhile.  With `stagger`, waves 0-3 fetch tile kt+1 before
+    // their MFMAs and their SIMD partners 4-7 between the two halves of theirs, so one wave's DMA issue runs under the other's
+    // matrix work (stage st^1 is free for the whole K-tile either way).  Pays for the 512x128 tile (+4-5 %); the 256-row tiles
+    // lose 3-11 % with it (their late waves then wait on DMA issued too close to the barrier).
+    const bool late = a.stagger && w >= 4;
+#ifdef VH_STAMP   // diagnostic build (`make stamp`, tools/stamp_conv.py): shader-cycle stamps around the segments of a K-tile, per wave
+    unsigned long long tacc[4] = {0, 0, 0, 0};
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t_;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return t_;
+    };
+#define VH_STAMP_AT(v) const unsigned long long v = stamp()
+#else
+#define VH_STAMP_AT(v)
+#endif
     for (int kt = 0; kt < KT; ++kt) {
         const int st = kt & 1;
-        if (kt + 1 < KT) {
-            if (chunk_major) {
-                if (++tap == 9) { tap = 0; cc += BK; }
-                setup_tap_fast(tap);
-            } else {
-                cc += BK;
-                if (cc >= a.cin_pad) {
-                    cc = 0;
-                    ++tap;
-                    setup_tap(tap);
+        VH_STAMP_AT(s0);
+        auto fetch_next = [&]() {
+            if (kt + 1 < KT) {
+                if (chunk_major) {
+                    if (++tap == 9) { tap = 0; cc += BK; }
+                    setup_tap_fast(tap);
+                } else {
+                    cc += BK;
+                    if (cc >= a.cin_pad) {
+                        cc = 0;
+                        ++tap;
+                        setup_tap(tap);
+                    }
                 }
+                issue(st ^ 1, tap, cc);
             }
-            issue(st ^ 1, tap, cc);
-        }
-        compute(st);
+        };
+        if (!late) fetch_next();
+        VH_STAMP_AT(s1);
+        compute(st, [&]() { if (late) fetch_next(); });
+        VH_STAMP_AT(s2);
         wait_dma();                                        // this wave's DMA of tile kt+1 has landed ...
+        VH_STAMP_AT(s3);
         __syncthreads();                                   // ... and so has every other wave's
+        VH_STAMP_AT(s4);
+#ifdef VH_STAMP
+        tacc[0] += s1 - s0; tacc[1] += s2 - s1; tacc[2] += s3 - s2; tacc[3] += s4 - s3;
+#endif
     }
+#ifdef VH_STAMP   // stamps go to the split-K scratch (unused when ksplit == 1), never into an output
+    if (a.scratch && a.ksplit == 1 && l == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.scratch) + ((size_t)blockIdx.x * 8 + w) * 6;
+        dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = tacc[3]; dbg[4] = (unsigned long long)KT; dbg[5] = 0;
+    }
+#endif
+#undef VH_STAMP_AT
 
     // the loop's last barrier has retired every read of the stages: reuse sA as 8 per-wave transpose patches
     float* patch = reinterpret_cast<float*>(&sA[0][0]) + w * (32 * 36);
@@ -455,6 +496,8 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
     const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
     const bool use16 = m16;
+    static const int stagger_env = getenv("VIVID_CONV_STAGGER") ? atoi(getenv("VIVID_CONV_STAGGER")) : -1;
+    k.stagger = stagger_env >= 0 ? stagger_env : (cfg == 2 ? 1 : 0);
     if (a.epi == VH_EPI_QKV && !use16) return vh_fail(VH_EINVAL, "vh_conv: the QKV epilogue exists only in the 16x16x32-MFMA kernels (unset VIVID_CONV_MFMA)");
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, use16, grid](hipStream_t s) -> int {
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, M16_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, M16_>), dim3(grid), dim3(512), 0, s, k)
