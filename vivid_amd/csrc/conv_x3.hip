@@ -252,8 +252,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     // ISSUING the 8-10 DMA pieces of a K-tile costs a wave 1100-1800 cycles against 1536 of MFMA issue, and that when both waves
     // of a SIMD do it right after the barrier the matrix pipe idles meanwhile.  With `stagger`, waves 0-3 fetch tile kt+1 before
     // their MFMAs and their SIMD partners 4-7 between the two halves of theirs, so one wave's DMA issue runs under the other's
-    // matrix work (stage st^1 is free for the whole K-tile either way).  Pays for the 512x128 tile (+4-5 %); the 256-row tiles
-    // lose 3-11 % with it (their late waves then wait on DMA issued too close to the barrier).
+    // matrix work (stage st^1 is free for the whole K-tile either way).  On for the 512x128 tile (+3..6 % on every device tried); for
+    // the 256-row tiles the sign depends on the device (+6..9 % on one MI355X, -1.5..3 % on two others, repeated A/B each), so
+    // they keep the plain order.  Issuing after ALL of the late waves' MFMAs instead is worse everywhere.
     const bool late = a.stagger && w >= 4;
 #ifdef VH_STAMP   // diagnostic build (`make stamp`, tools/stamp_conv.py): shader-cycle stamps around the segments of a K-tile, per wave
     unsigned long long tacc[4] = {0, 0, 0, 0};
