@@ -249,6 +249,8 @@ def main():
                 out["roofline_attention"] = {"bound": "mfma", "achieved": ka["tflops"], "peak": pk, "unit": "TFLOP/s",
                                              "frac": ka["tflops"] / pk, "avg_launch_ms": va["ms"] / va["launches"],
                                              "traffic": traffic.get("attention"), "share_of_step": ka["ms_per_step"] / out["ms_per_step"]}
+            from vivid_amd import engine as _eng
+            out["config"]["conv_stagger_autotuned"] = {str(k): v for k, v in _eng._TUNED.items()}   # per device: 1 = staggered DMA issue won the start-up A/B
             out["kernels"] = kern
             tot_fl = sum(v["flops"] for v in fam.values())
             out["whole_step_tflops"] = tot_fl / elapsed / 1e12

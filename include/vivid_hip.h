@@ -143,6 +143,9 @@ typedef struct {
     const float* res; int res_up;          /* MPSUM */
     float ta, tb, clip;                    /* clip <= 0: no clipping */
     const vh_qkv_epilogue* qkv;            /* VH_EPI_QKV only */
+    int stagger;                           /* VH_CONV_GLDS256 scheduling hint: 0 = library default, 1 = stagger the DMA issue of SIMD partner
+                                              waves, 2 = do not.  Results are identical; which is faster for the 256-row tiles depends on the
+                                              device, so a host may time both once and pass its choice. */
 } vh_conv_args;
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
 

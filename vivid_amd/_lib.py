@@ -40,7 +40,7 @@ class ConvArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
                 ("prec", C.c_int), ("kernel", C.c_int), ("epi", C.c_int),
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
-                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p)]
+                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p), ("stagger", C.c_int)]
 
 
 class PixnormArgs(C.Structure):

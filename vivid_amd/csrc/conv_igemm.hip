@@ -251,6 +251,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(!a.up || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: up needs even output size");
     VH_REQUIRE(a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU, "vh_conv: bad prologue");
     VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_QKV, "vh_conv: bad epilogue");
+    VH_REQUIRE(a.stagger >= 0 && a.stagger <= 2, "vh_conv: stagger must be 0, 1 or 2");
     if (a.epi == VH_EPI_QKV) {
         VH_REQUIRE(a.qkv && a.taps == 1 && a.kernel == VH_CONV_GLDS256 && !a.out && !a.out_s8, "vh_conv: QKV epilogue needs qkv args, a 1x1 GLDS convolution and no other output");
         const vh_qkv_epilogue& e = *a.qkv;

@@ -498,7 +498,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
     const bool use16 = m16;
     static const int stagger_env = getenv("VIVID_CONV_STAGGER") ? atoi(getenv("VIVID_CONV_STAGGER")) : -1;
-    k.stagger = stagger_env >= 0 ? stagger_env : (cfg == 2 ? 1 : 0);
+    k.stagger = stagger_env >= 0 ? stagger_env : a.stagger == 1 ? 1 : a.stagger == 2 ? 0 : (cfg == 2 ? 1 : 0);
     if (a.epi == VH_EPI_QKV && !use16) return vh_fail(VH_EINVAL, "vh_conv: the QKV epilogue exists only in the 16x16x32-MFMA kernels (unset VIVID_CONV_MFMA)");
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, use16, grid](hipStream_t s) -> int {
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, M16_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, M16_>), dim3(grid), dim3(512), 0, s, k)
