@@ -161,6 +161,30 @@ def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
     assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
 
 
+@pytest.mark.parametrize("rows,h,w,cin,cout", [(2, 64, 64, 128, 256), (1, 128, 128, 64, 128), (4, 32, 32, 256, 384)])
+def test_conv_stagger_hint_does_not_change_results(ctx, rows, h, w, cin, cout):
+    """vh_conv_args.stagger is a scheduling hint (which wave issues its DMA when): outputs are bit-identical."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(rows, h, w, cin, generator=g).cuda()
+    wgt = torch.randn(cout, cin, 3, 3, generator=g)
+    M = rows * h * w
+    xs8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=x.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+    outs = []
+    for hint in (0, 1, 2):
+        out = torch.empty(M, cout, device="cuda")
+        ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                      taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                      scratch=_scratch(), scratch_floats=1 << 22, cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0,
+                                      prec=1, kernel=1, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0, stagger=hint))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 MODES = [(0, 0), (1, 0), (1, 1)]     # (prec, kernel): fp32 tile128 | bf16x3 tile128 | bf16x3 glds256
 
 
