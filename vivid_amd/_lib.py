@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvivid_hip.so")
+# VIVID_HIP_LIB: load another build of the same ABI instead (diagnostic builds: `make stamp`, A/B of compile-time knobs)
+LIB_PATH = os.environ.get("VIVID_HIP_LIB") or os.path.join(_HERE, "libvivid_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 

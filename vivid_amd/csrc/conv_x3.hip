@@ -17,6 +17,10 @@
 #include <algorithm>
 #include <cstdlib>
 
+#ifndef VH_EPI_PD
+#define VH_EPI_PD 1          // epilogue blocks whose residual / cvec values are in flight ahead of the one being written (3 measured the same)
+#endif
+
 namespace {
 using namespace vhconv;
 
@@ -409,18 +413,23 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         e.out_s8 = nullptr;
     }
     if constexpr (M16) {
-        // block b's residual / cvec values are requested while block b-1 is written out (conv_epilogue_prefetch)
-        EpiAux nxt = conv_epilogue_prefetch(e, m0 + wm * MI * 32, n0 + wn * NI * 32, l);
+        // the residual / cvec values of block b are requested PD blocks before it is written out (conv_epilogue_prefetch): the
+        // fragment registers are dead by now, so a few blocks' worth of values fit
+        constexpr int NB = MI * NI;
+        constexpr int PD = VH_EPI_PD < NB ? VH_EPI_PD : NB;
+        EpiAux ring[PD];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
+        for (int b = 0; b < PD; ++b)
+            ring[b] = conv_epilogue_prefetch(e, m0 + (wm * MI + b / NI) * 32, n0 + (wn * NI + b % NI) * 32, l);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const EpiAux cur = nxt;
-                const int b1 = mi * NI + ni + 1;                                   // the block after this one
-                if (b1 < MI * NI) nxt = conv_epilogue_prefetch(e, m0 + (wm * MI + b1 / NI) * 32, n0 + (wn * NI + b1 % NI) * 32, l);
-                conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
-                                          acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l, &cur);
-            }
+        for (int b = 0; b < NB; ++b) {
+            const int mi = b / NI, ni = b % NI;
+            const EpiAux cur = ring[b % PD];
+            if (b + PD < NB)
+                ring[b % PD] = conv_epilogue_prefetch(e, m0 + (wm * MI + (b + PD) / NI) * 32, n0 + (wn * NI + (b + PD) % NI) * 32, l);
+            conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
+                                      acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l, &cur);
+        }
     } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
