@@ -37,7 +37,8 @@ extern "C" {
 typedef struct vh_ctx vh_ctx;
 typedef struct vh_plan vh_plan;
 
-int vh_abi_version(void);
+#define VH_ABI_VERSION 2
+int vh_abi_version(void);                                /* == VH_ABI_VERSION of the header the library was built from */
 const char* vh_last_error(void);
 
 /* stream: a hipStream_t (0 = default stream). */
@@ -59,6 +60,7 @@ int vh_profile_read_list(vh_ctx* ctx, int max_n, int* tags, double* ms, double* 
 
 int vh_plan_begin(vh_ctx* ctx);
 int vh_plan_end(vh_ctx* ctx, vh_plan** out);
+int vh_plan_abort(vh_ctx* ctx);                          /* drop the plan being recorded (an op failed validation); no-op when not recording */
 int vh_plan_capture_graph(vh_ctx* ctx, vh_plan* plan);   /* optional: replay through one hipGraphLaunch (launch-bound shapes) */
 int vh_plan_run(vh_ctx* ctx, const vh_plan* plan);
 int vh_plan_num_ops(const vh_plan* plan);
@@ -144,9 +146,19 @@ typedef struct {
     float ta, tb, clip;                    /* clip <= 0: no clipping */
     const vh_qkv_epilogue* qkv;            /* VH_EPI_QKV only */
     int stagger;                           /* VH_CONV_GLDS256 scheduling hint: 0 = library default, 1 = stagger the DMA issue of SIMD partner
-                                              waves, 2 = do not.  Results are identical; which is faster for the 256-row tiles depends on the
-                                              device, so a host may time both once and pass its choice. */
+                                              waves, 2 = do not.  Results are identical (bit for bit). */
+    int korder;                            /* VH_CONV_GLDS256, taps == 9: order in which the K loop walks (tap, 32-channel chunk) tiles.
+                                              VH_KORDER_AUTO: by input size (chunk-major once the input outgrows the Infinity Cache);
+                                              VH_KORDER_TAP: all chunks of tap 0, then tap 1, ...; VH_KORDER_CHUNK: the 9 taps of chunk 0, then of
+                                              chunk 1, ... (not with `up`: falls back to tap-major).  The sum is the same set of products in a
+                                              different order: results agree to fp32 rounding, not bit for bit. */
+    int tile;                              /* VH_CONV_GLDS256: workgroup tile, VH_TILE_AUTO (by shape and grid size) or a forced shape
+                                              (pixels x output channels): VH_TILE_256x128, VH_TILE_256x256 (needs cout % 256 == 0),
+                                              VH_TILE_512x128, VH_TILE_512x64 (needs cout <= 64).  A forced shape disables split-K unless
+                                              the grid is small; every shape computes the same sums in the same order. */
 } vh_conv_args;
+enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
+enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4 };
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
 
 /* ---- K6 (+K9): pixel norm with optional 2x2 mean pooling ------------------
@@ -291,8 +303,31 @@ typedef struct {
     const float* freqs; const float* phases;
     int rows, s;
     float* grid_feat; float* warp_feat;
+    const float* nonzero_flag;   /* optional, from vh_nonzero_flag over src[:, :3]: when it reads 0 (the source is all zero) both
+                                    outputs are zero grids, the shortcut of training/models.py:647-648, decided on the device */
 } vh_warp_args;
 int vh_warp_features(vh_ctx* ctx, const vh_warp_args* a);
+
+/* flag[0] = 1.0f if any of the first c_used channels of any row of the NCHW tensor `in` [rows][c_total][hw] is non-zero, else
+ * 0.0f: `torch.all(src[:, :3] == 0)` of training/models.py:647 without a host synchronisation. */
+typedef struct {
+    const float* in; int rows, c_used, c_total, hw;
+    float* flag;
+} vh_nonzero_args;
+int vh_nonzero_flag(vh_ctx* ctx, const vh_nonzero_args* a);
+
+/* ---- resample with a general filter (training/models.py:48-61), NHWC fp32 -----------------------------
+ * The default filter [1,1] (2x2 mean / nearest replication) is fused into vh_pixnorm (pool) and vh_conv (up); any other
+ * even-length `resample_filter` of Block (:139) goes through this kernel.  taps = f / sum(f):
+ *   down: depthwise stride-2 correlation with outer(taps, taps), padding (L-1)/2      [rows][h][w][c] -> [rows][h/2][w/2][c]
+ *   up  : depthwise stride-2 transposed convolution with 4*outer(taps, taps)          [rows][h][w][c] -> [rows][2h][2w][c] */
+typedef struct {
+    const float* in; float* out;
+    int rows, h, w, c;          /* INPUT geometry */
+    int up;
+    int ntaps; float taps[8];
+} vh_resample_args;
+int vh_resample(vh_ctx* ctx, const vh_resample_args* a);
 
 /* ---- K17: pixel codec (training/encoders.py:58-62) ---------------------------
  * decode=0: out_f32[i] = in_u8[i] / 127.5 - 1          (StandardRGBEncoder.encode_latents)
@@ -350,6 +385,28 @@ typedef struct {
     float* x_next;
 } vh_sampler_step_args;
 int vh_sampler_step(vh_ctx* ctx, const vh_sampler_step_args* a);
+
+/* ---- FID / PSNR statistics (calculate_metrics.py:147, 158-172) -------------------------------------------
+ * vh_moments: outer[fa][fb] += A^T B and (optionally) sum_a[fa] += column sums of A, for detector features A [n][fa],
+ * B [n][fb] (fp32, row-major; B may be A).  Products and sums are fp64 on v_mfma_f64_16x16x4_f64, i.e. exactly the
+ * reference's `features.to(float64)`; `features.T @ features` is A == B, the off-diagonal block of the joint
+ * [image | source] moments is A = image features, B = source features.  The accumulators persist across batches and are
+ * all_reduced once at the end (calculate_metrics.py:176-182). */
+typedef struct {
+    const float* a; const float* b;
+    int n, fa, fb;
+    double* outer; double* sum_a;          /* sum_a may be NULL */
+} vh_moments_args;
+int vh_moments(vh_ctx* ctx, const vh_moments_args* a);
+
+/* acc[0] += sum over images of 10*log10(255^2 / mean((x - y)^2)), images as [images][elems] uint8 or fp32 on the
+ * [0,255] scale (calculate_metrics.py:147). */
+enum { VH_U8 = 0, VH_F32 = 1 };
+typedef struct {
+    const void* x; const void* y; int images; size_t elems; int dtype;
+    double* acc;
+} vh_psnr_args;
+int vh_psnr_sum(vh_ctx* ctx, const vh_psnr_args* a);
 
 #ifdef __cplusplus
 }

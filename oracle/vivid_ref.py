@@ -41,16 +41,28 @@ def normalize(x: Tensor, dim=None, eps: float = 1e-4) -> Tensor:
     return x / n
 
 
-def resample(x: Tensor, mode: str) -> Tensor:
-    """training/models.py:48-61 with f=[1,1]: 'down' is a depthwise stride-2
-    conv with a constant 0.25 filter (= 2x2 mean), 'up' a depthwise transposed
-    conv with a ones filter (= 2x nearest replicate)."""
+def resample(x: Tensor, mode: str, f=(1, 1)) -> Tensor:
+    """training/models.py:48-61.  With the default f=[1,1]: 'down' is a depthwise stride-2 conv with a constant
+    0.25 filter (= 2x2 mean), 'up' a depthwise transposed conv with a ones filter (= 2x nearest replicate).
+    Any other even-length filter: g = outer(f, f) / sum(f)^2; 'down' = depthwise stride-2 correlation with g,
+    padding (len-1)//2; 'up' = depthwise stride-2 transposed convolution with 4 g, same padding."""
     if mode == "keep":
         return x
+    if tuple(float(v) for v in f) == (1.0, 1.0):
+        if mode == "down":
+            return F.avg_pool2d(x, 2)
+        assert mode == "up"
+        return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    f1 = torch.tensor([float(v) for v in f], dtype=torch.float32)
+    assert f1.ndim == 1 and len(f1) % 2 == 0
+    pad = (len(f1) - 1) // 2
+    f1 = f1 / f1.sum()
+    c = x.shape[1]
+    g = torch.outer(f1, f1)[None, None].to(x.dtype).tile([c, 1, 1, 1])
     if mode == "down":
-        return F.avg_pool2d(x, 2)
+        return F.conv2d(x, g, groups=c, stride=2, padding=pad)
     assert mode == "up"
-    return x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    return F.conv_transpose2d(x, g * 4, groups=c, stride=2, padding=pad)
 
 
 def mp_silu(x: Tensor) -> Tensor:
@@ -101,6 +113,7 @@ DEFAULTS = dict(
     label_balance=0.5, concat_balance=0.5, res_balance=0.3, attn_balance=0.3, clip_act=256.0,
     sigma_data=0.5, logvar_channels=128, super_res=False, no_time_enc=None, depth_input=False,
     warp_depth_coor=False, uncond=None, noisy_sr=0.25,
+    channel_mult_noise=None, channel_mult_emb=None, resample_filter=(1, 1),
 )
 
 
@@ -187,7 +200,7 @@ def block_forward(sd: Dict[str, Tensor], p: str, info: dict, cfg: dict, x: Tenso
                   f1: Optional[Tensor] = None, f2: Optional[Tensor] = None, explicit_attn: bool = False,
                   taps: Optional[dict] = None) -> Tensor:
     """Block.forward training/models.py:165-206 / XAttnBlock.forward :251-315."""
-    x = resample(x, info["resample"])
+    x = resample(x, info["resample"], cfg.get("resample_filter", (1, 1)))
     has_skip = info["cin"] != info["cout"]
     if info["flavor"] == "enc":
         if has_skip:

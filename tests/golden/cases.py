@@ -35,6 +35,12 @@ CASES = {
     # warp_depth_coor together do not run in the reference (encoder conv expects 133 channels, gets 132).
     "tiny_depth": dict(cfg=NetConfig(img_resolution=16, model_channels=64, attn_resolutions=(8,),
                                      depth_input=True), seed=12, B=1, sigmas=[1.0]),
+    # the all-zero-source shortcut of training/models.py:647-648: src[:, :3] == 0 everywhere -> zero warp grids
+    "tiny_warp_zero": dict(cfg=NetConfig(img_resolution=16, model_channels=64, attn_resolutions=(8,),
+                                         warp_depth_coor=True), seed=11, B=1, sigmas=[2.0], zero_src=True),
+    # non-default constructor surface: noise / embedding widths (:340-341) and a 4-tap resampling filter (:139, :48-61)
+    "tiny_opts": dict(cfg=NetConfig(img_resolution=16, model_channels=64, extra_attn=1, channel_mult_noise=2,
+                                    channel_mult_emb=3, resample_filter=(1.0, 3.0, 3.0, 1.0)), seed=17, B=1, sigmas=[5.0, 0.3]),
     # upstream single-source variant kept by the reference under experiments/code
     "tiny_vanilla": dict(cfg=NetConfig(**_T, target_label_dim=20), gcfg=NetConfig(**_T, target_label_dim=20, uncond=True),
                          seed=13, B=2, sigmas=[5.0, 0.2], sampler=dict(num_steps=3, guidance=1.5), snapshot=True),
@@ -56,6 +62,8 @@ def make_inputs(case: dict) -> dict:
     g = torch.Generator("cpu").manual_seed(1000 + case["seed"])
     out = {}
     src = torch.rand(rows, 3, R, R, generator=g) * 2 - 1
+    if case.get("zero_src"):
+        src = torch.zeros_like(src)
     if cfg.depth_input or cfg.warp_depth_coor:
         depth = torch.rand(rows, 1, R, R, generator=g) * 4 + 1
         src = torch.cat([src, depth], dim=1)

@@ -58,6 +58,12 @@ def build_ref_net(models, cfg: NetConfig, seed, snapshot=False):
               extra_attn=cfg.extra_attn, use_fp16=False, super_res=cfg.super_res,
               no_time_enc=cfg.no_time_enc, depth_input=cfg.depth_input,
               warp_depth_coor=cfg.warp_depth_coor, uncond=cfg.uncond, noisy_sr=cfg.noisy_sr)
+    if cfg.channel_mult_noise is not None:
+        kw["channel_mult_noise"] = cfg.channel_mult_noise
+    if cfg.channel_mult_emb is not None:
+        kw["channel_mult_emb"] = cfg.channel_mult_emb
+    if tuple(cfg.resample_filter) != (1.0, 1.0):
+        kw["resample_filter"] = list(cfg.resample_filter)
     if snapshot:
         kw["label_dim"] = cfg.source_label_dim
     else:

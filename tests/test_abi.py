@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.OPS) | set(_lib.CONTROL)
     for name in declared:
         assert hasattr(L, name), name
-    assert L.vh_abi_version() == 1
+    assert L.vh_abi_version() == _lib.ABI_VERSION
 
 
 def test_struct_mirrors_match_header_field_counts():
@@ -31,7 +31,9 @@ def test_struct_mirrors_match_header_field_counts():
              "vh_qkv_split_args": _lib.QkvSplitArgs, "vh_split_args": _lib.SplitArgs, "vh_attention_args": _lib.AttentionArgs, "vh_embed_args": _lib.EmbedArgs,
              "vh_linear_args": _lib.LinearArgs, "vh_segment": _lib.Segment, "vh_assemble_args": _lib.AssembleArgs,
              "vh_precond_out_args": _lib.PrecondOutArgs, "vh_warp_args": _lib.WarpArgs,
-             "vh_sampler_step_args": _lib.SamplerStepArgs, "vh_qkv_epilogue": _lib.QkvEpilogue, "vh_codec_args": _lib.CodecArgs, "vh_add_depth_args": _lib.AddDepthArgs, "vh_resize_args": _lib.ResizeArgs}
+             "vh_sampler_step_args": _lib.SamplerStepArgs, "vh_qkv_epilogue": _lib.QkvEpilogue, "vh_codec_args": _lib.CodecArgs, "vh_add_depth_args": _lib.AddDepthArgs, "vh_resize_args": _lib.ResizeArgs,
+             "vh_nonzero_args": _lib.NonzeroArgs, "vh_resample_args": _lib.ResampleArgs, "vh_moments_args": _lib.MomentsArgs,
+             "vh_psnr_args": _lib.PsnrArgs}
     for cname, st in pairs.items():
         m = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + r"\s*;", h, flags=re.S)
         assert m, cname
@@ -60,6 +62,14 @@ def test_argument_validation_without_gpu():
         ctx.plan_begin()
     plan = ctx.plan_end()
     assert plan.num_ops == 0
+    # an op refused while recording: vh_plan_abort drops the partial plan and the context records again afterwards
+    ctx.plan_begin()
+    with pytest.raises(_lib.VividHipError, match="taps"):
+        ctx.call("vh_conv", _lib.ConvArgs(taps=5))
+    ctx.plan_abort()
+    ctx.plan_abort()                      # no-op when not recording
+    ctx.plan_begin()
+    assert ctx.plan_end().num_ops == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

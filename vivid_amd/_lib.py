@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIVID_HIP_LIB") or os.path.join(_HERE, "libvivid_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
+ABI_VERSION = 2          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
 
 
 class VividHipError(RuntimeError):
@@ -41,7 +42,8 @@ class ConvArgs(C.Structure):
                 ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
                 ("prec", C.c_int), ("kernel", C.c_int), ("epi", C.c_int),
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
-                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p), ("stagger", C.c_int)]
+                ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p), ("stagger", C.c_int),
+                ("korder", C.c_int), ("tile", C.c_int)]
 
 
 class PixnormArgs(C.Structure):
@@ -101,7 +103,28 @@ class PrecondOutArgs(C.Structure):
 class WarpArgs(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("src_c", C.c_int), ("depth_ch", C.c_int), ("geometry", C.c_void_p),
                 ("mean", C.c_float * 20), ("std", C.c_float * 20), ("freqs", C.c_void_p), ("phases", C.c_void_p),
-                ("rows", C.c_int), ("s", C.c_int), ("grid_feat", C.c_void_p), ("warp_feat", C.c_void_p)]
+                ("rows", C.c_int), ("s", C.c_int), ("grid_feat", C.c_void_p), ("warp_feat", C.c_void_p),
+                ("nonzero_flag", C.c_void_p)]
+
+
+class NonzeroArgs(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("rows", C.c_int), ("c_used", C.c_int), ("c_total", C.c_int), ("hw", C.c_int),
+                ("flag", C.c_void_p)]
+
+
+class ResampleArgs(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int),
+                ("up", C.c_int), ("ntaps", C.c_int), ("taps", C.c_float * 8)]
+
+
+class MomentsArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("n", C.c_int), ("fa", C.c_int), ("fb", C.c_int),
+                ("outer", C.c_void_p), ("sum_a", C.c_void_p)]
+
+
+class PsnrArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("images", C.c_int), ("elems", C.c_size_t), ("dtype", C.c_int),
+                ("acc", C.c_void_p)]
 
 
 class CodecArgs(C.Structure):
@@ -133,11 +156,12 @@ OPS = {
     "vh_linear": LinearArgs, "vh_assemble": AssembleArgs, "vh_precond_out": PrecondOutArgs,
     "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs, "vh_codec": CodecArgs, "vh_add_depth": AddDepthArgs,
     "vh_resize_bilinear": ResizeArgs, "vh_resize": ResizeArgs,
+    "vh_nonzero_flag": NonzeroArgs, "vh_resample": ResampleArgs, "vh_moments": MomentsArgs, "vh_psnr_sum": PsnrArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
 CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
-           "vh_plan_begin", "vh_plan_end", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
+           "vh_plan_begin", "vh_plan_end", "vh_plan_abort", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
 _lib = None
 
@@ -153,6 +177,9 @@ def lib():
             f"or `make -C vivid_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
     L.vh_abi_version.restype = C.c_int
+    if L.vh_abi_version() != ABI_VERSION:
+        raise VividHipError(f"{LIB_PATH} was built from another version of include/vivid_hip.h (library ABI {L.vh_abi_version()}, "
+                            f"bindings {ABI_VERSION}): rebuild it with `make -C vivid_amd/csrc`")
     L.vh_last_error.restype = C.c_char_p
     L.vh_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.vh_ctx_destroy.argtypes = [C.c_void_p]
@@ -161,6 +188,7 @@ def lib():
     L.vh_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.vh_plan_begin.argtypes = [C.c_void_p]
+    L.vh_plan_abort.argtypes = [C.c_void_p]
     L.vh_plan_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.vh_plan_run.argtypes = [C.c_void_p, C.c_void_p]
     L.vh_plan_capture_graph.argtypes = [C.c_void_p, C.c_void_p]
@@ -220,6 +248,9 @@ class Context:
 
     def plan_begin(self):
         check(self._L.vh_plan_begin(self.handle), "vh_plan_begin")
+
+    def plan_abort(self):
+        check(self._L.vh_plan_abort(self.handle), "vh_plan_abort")
 
     def plan_end(self) -> "Plan":
         p = C.c_void_p()

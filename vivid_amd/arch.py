@@ -27,6 +27,9 @@ class NetConfig:
     num_blocks: int = 3
     attn_resolutions: Tuple[int, ...] = (16, 8)
     extra_attn: Optional[int] = None
+    channel_mult_noise: Optional[int] = None   # cnoise = model_channels * this (None: first level's channels, :340)
+    channel_mult_emb: Optional[int] = None     # cemb = model_channels * this (None: widest level, :341)
+    resample_filter: Tuple[float, ...] = (1.0, 1.0)   # Block's up/down filter (:139, :48-61); even length
     label_balance: float = 0.5
     concat_balance: float = 0.5
     res_balance: float = 0.3
@@ -120,8 +123,10 @@ def unet_spec(cfg: NetConfig, *, role: str) -> UNetSpec:
         if cfg.super_res:
             in_ch = 2 * (in_ch - 1) + 1                              # :581
     cblock = [cfg.model_channels * m for m in cfg.channel_mult]
+    cnoise = cfg.model_channels * cfg.channel_mult_noise if cfg.channel_mult_noise is not None else cblock[0]   # :340
+    cemb = cfg.model_channels * cfg.channel_mult_emb if cfg.channel_mult_emb is not None else max(cblock)       # :341
     spec = UNetSpec(img_resolution=R, in_channels=in_ch, label_dim=label_dim,
-                    cnoise=cblock[0], cemb=max(cblock), channels_per_head=cph)
+                    cnoise=cnoise, cemb=cemb, channels_per_head=cph)
     xattn = role == "unet"
 
     def heads_of(attn, cout):

@@ -6,7 +6,7 @@ std::string& vh_err() {
     return e;
 }
 
-extern "C" int vh_abi_version(void) { return 1; }
+extern "C" int vh_abi_version(void) { return VH_ABI_VERSION; }
 
 extern "C" const char* vh_last_error(void) { return vh_err().c_str(); }
 
@@ -116,6 +116,14 @@ extern "C" int vh_plan_end(vh_ctx* ctx, vh_plan** out) {
     ctx->recording = false;
     *out = ctx->cur;
     ctx->cur = nullptr;
+    return VH_OK;
+}
+
+extern "C" int vh_plan_abort(vh_ctx* ctx) {
+    if (!ctx) return vh_fail(VH_EINVAL, "vh_plan_abort: null context");
+    delete ctx->cur;
+    ctx->cur = nullptr;
+    ctx->recording = false;
     return VH_OK;
 }
 

@@ -467,12 +467,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long lo
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
     // 256x256 tiles when Cout allows it and the grid still gives every CU (256) a workgroup; otherwise 256x128
-    const bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
+    bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
     // 512x128 tiles (same 128x64 wave tile as the wide config) when only the narrow N fits and M is large
-    const bool tall = !wide && ((M + 511) / 512) * ((a.cout + 127) / 128) >= 512;
+    bool tall = !wide && ((M + 511) / 512) * ((a.cout + 127) / 128) >= 512;
     // 512x64 tiles (8 waves of 64x64) for Cout <= 64 at large M - the full-resolution layers of the super-resolution net,
     // where a 128-wide tile would spend half of its MFMAs and B traffic on zero columns
-    const bool slim = a.cout <= 64 && (M + 511) / 512 >= 512;
+    bool slim = a.cout <= 64 && (M + 511) / 512 >= 512;
+    if (a.tile != VH_TILE_AUTO) {                          // caller's choice (tests sweep every shape on small problems)
+        if (a.tile == VH_TILE_256x256 && a.cout % 256) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_256x256 needs cout %% 256 == 0 (got %d)", a.cout);
+        if (a.tile == VH_TILE_512x64 && a.cout > 64) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_512x64 needs cout <= 64 (got %d)", a.cout);
+        wide = a.tile == VH_TILE_256x256; tall = a.tile == VH_TILE_512x128; slim = a.tile == VH_TILE_512x64;
+    }
     const int BN = wide ? 256 : slim ? 64 : 128, BMt = (tall || slim) ? 512 : 256;
     const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
@@ -498,9 +503,11 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // chunk-major K order when the input does not stay in the 256 MB Infinity Cache either: with tap-major order each tap's
     // re-read then comes from HBM.  Measured: +7..10 % at 256x256 (0.5-1 GB inputs), +3..4 % at 128x128 (0.27-0.54 GB),
     // +1.6 % at 0.2 GB, -2 % at 67 MB (the per-K-tile pointer selection costs VALU and buys nothing there).
+    // vh_conv_args.korder overrides the size rule; VIVID_CONV_KORDER (0 tap / 1 chunk) overrides both (A/B runs).
     static const int korder_env = getenv("VIVID_CONV_KORDER") ? atoi(getenv("VIVID_CONV_KORDER")) : -1;
     const bool big_input = (double)M * a.cin_pad * 4.0 > 1.5e8;
-    k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : (big_input ? 1 : 0)) : 0;
+    const int korder_arg = a.korder == VH_KORDER_TAP ? 0 : a.korder == VH_KORDER_CHUNK ? 1 : (big_input ? 1 : 0);
+    k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : korder_arg) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
     static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);

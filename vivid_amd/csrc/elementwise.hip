@@ -387,6 +387,11 @@ __global__ __launch_bounds__(256) void warp_features_k(vh_warp_args a, long long
     const int ss = a.s * a.s;
     const int r = (int)(pix / ss), p = (int)(pix - (long long)r * ss);
     const int yi = p / a.s, xi = p - yi * a.s;
+    if (a.nonzero_flag && *a.nonzero_flag == 0.f) {      // all-zero source: zero grids (training/models.py:647-648)
+        a.grid_feat[i] = 0.f;
+        a.warp_feat[i] = 0.f;
+        return;
+    }
     const int axis = ch >> 6, kf = ch & 63;
     const float g0 = yi + 0.5f, g1 = xi + 0.5f;     // meshgrid 'ij': coordinate 0 = row index
     float g[20];

@@ -128,6 +128,7 @@ class Engine:
         # attn_qkv / x_attn_kv write q, k, v^T from their own epilogue (needs the 16x16x32-MFMA glds kernel)
         self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0" and os.environ.get("VIVID_CONV_MFMA", "16") != "32"
         self.cfg = cfg
+        self.std_filter = tuple(float(v) for v in cfg.resample_filter) == (1.0, 1.0)
         self.dual = dual_source
         self.nsrc = 2 if dual_source else 1
         self.enc_spec: Optional[UNetSpec] = None if cfg.uncond else unet_spec(cfg, role="encoder")
@@ -340,6 +341,21 @@ class Engine:
                    f"rows={rows} {h}x{w} c={ctot} raw={int(raw_too)}")
         return (out, raw) if raw_too else out
 
+    def _resample(self, x: Buf, up: bool) -> Buf:
+        """resample() with a non-default filter (training/models.py:48-61) as its own launch; the default [1,1] is fused
+        into vh_pixnorm (down) and vh_conv (up) instead."""
+        rows, h, w, c = x.shape
+        f = [float(v) for v in self.cfg.resample_filter]
+        if len(f) % 2 or not 2 <= len(f) <= 8:
+            raise ValueError(f"resample_filter must have 2, 4, 6 or 8 taps (the reference asserts an even length, :52); got {f}")
+        out = self._alloc(rows, h * 2, w * 2, c) if up else self._alloc(rows, h // 2, w // 2, c)
+        a = L.ResampleArgs(inp=x.ptr, out=out.ptr, rows=rows, h=h, w=w, c=c, up=1 if up else 0, ntaps=len(f))
+        tot = sum(f)
+        for i, v in enumerate(f):
+            a.taps[i] = v / tot
+        self._call("vh_resample", a, f"rows={rows} {h}x{w} c={c} up={int(up)}")
+        return out
+
     def _mp_sum_coeffs(self, t: float):
         n = math.sqrt((1 - t) ** 2 + t ** 2)
         return (1 - t) / n, t / n
@@ -370,9 +386,12 @@ class Engine:
         if b.flavor == "enc":
             xs = self._alloc(rows, R, R, C) if x3 else None      # S8 of mp_silu(xn): conv_res0's input
             xs_ptr = xs.ptr if xs is not None else None
-            if b.resample == "down":
+            if b.resample == "down" and self.std_filter:
                 xn = self._alloc(rows, R, R, C)
                 self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=1, norm=1, out_s8=xs_ptr))
+            elif b.resample == "down":                           # general FIR filter (:48-59), then the plain pixel norm
+                xn = self._resample(x, up=False)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=0, norm=1, out_s8=xs_ptr))
             elif has_skip_conv:
                 if x3:
                     xr = self._split([(x, 1.0)], 0)
@@ -395,6 +414,10 @@ class Engine:
             self._free(xn)
         else:
             up = 1 if b.resample == "up" else 0
+            xup = None
+            if up and not self.std_filter:                         # general FIR filter (:60-61): materialise the upsampled input
+                x = xup = self._resample(x, up=True)
+                up = 0
             if skip is not None:                                   # mp_cat :78-84
                 t = cfg.concat_balance
                 Na, Nb = x.shape[-1], skip.shape[-1]
@@ -429,6 +452,7 @@ class Engine:
                            res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
             self._free(y)
             self._free(xsk)
+            self._free(xup)
         if res1_s8 or fin_s8:
             out, r_s8 = r
         else:
@@ -598,7 +622,14 @@ class Engine:
                 self._A.base_ptr = self._backing.data_ptr()
                 if self.hook is None:
                     self.ctx.plan_begin()
-            io = self._walk(mode, B, has_cond, want_logvar, fill if emit else None)
+            try:
+                io = self._walk(mode, B, has_cond, want_logvar, fill if emit else None)
+            except BaseException:
+                # an op was refused (unsupported shape, alignment): leave the context usable and the real error visible
+                if emit and self.hook is None:
+                    self.ctx.plan_abort()
+                self._emit, self._A, self._backing = False, None, None
+                raise
             if not emit:
                 peak = self._A.peak
             else:
@@ -646,14 +677,18 @@ class Engine:
             sgrid = self._alloc(rows_all, R, R, 128)
             dgrid = self._alloc(rows_all, R, R, 128)
             mean, std = geometry_stats(R)
+            # `if torch.all(src[:, :3] == 0): zero grids` (:647-648) decided on the device: a flag kernel, read by the warp kernel
+            flag = self._alloc(1)
+            self._call("vh_nonzero_flag", L.NonzeroArgs(inp=io["src"].ptr, rows=rows_all, c_used=3, c_total=src_c, hw=R * R, flag=flag.ptr))
             wa = L.WarpArgs(depth=io["src"].ptr, src_c=src_c, depth_ch=3, geometry=io["geometry"].ptr,
                             freqs=self._params["logvar_fourier.freqs"].data_ptr(),
                             phases=self._params["logvar_fourier.phases"].data_ptr(),
-                            rows=rows_all, s=R, grid_feat=sgrid.ptr, warp_feat=dgrid.ptr)
+                            rows=rows_all, s=R, grid_feat=sgrid.ptr, warp_feat=dgrid.ptr, nonzero_flag=flag.ptr)
             for i in range(20):
                 wa.mean[i] = float(mean[i])
                 wa.std[i] = float(std[i])
             self._call("vh_warp_features", wa)
+            self._free(flag)
 
         if need_enc:
             spec = self.enc_spec

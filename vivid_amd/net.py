@@ -59,12 +59,13 @@ class NVPrecond(torch.nn.Module):
                 raise TypeError(f"NVPrecond: unexpected keyword {k!r}")
         if unet_kwargs.get("epipolar_attention_bias"):
             raise NotImplementedError("epipolar attention bias is dead code at HEAD (SURVEY 2.1 #13) and not built")
-        if unet_kwargs.get("channel_mult_noise") is not None or unet_kwargs.get("channel_mult_emb") is not None:
-            raise NotImplementedError("channel_mult_noise / channel_mult_emb overrides are not supported")
-        if list(unet_kwargs.get("resample_filter", [1, 1])) != [1, 1]:
-            raise NotImplementedError("only the reference's default resample_filter [1,1] is built")
+        if unet_kwargs.get("dropout"):
+            raise NotImplementedError("dropout is a training-time option (training/models.py:178); this is the inference path")
         kw = {k: v for k, v in unet_kwargs.items() if k in ("model_channels", "num_blocks", "extra_attn", "label_balance",
-                                                             "concat_balance", "res_balance", "attn_balance", "clip_act")}
+                                                             "concat_balance", "res_balance", "attn_balance", "clip_act",
+                                                             "channel_mult_noise", "channel_mult_emb")}
+        if "resample_filter" in unet_kwargs:
+            kw["resample_filter"] = tuple(float(v) for v in unet_kwargs["resample_filter"])
         if "channel_mult" in unet_kwargs:
             kw["channel_mult"] = tuple(unet_kwargs["channel_mult"])
         if "attn_resolutions" in unet_kwargs:
@@ -106,7 +107,8 @@ class NVPrecond(torch.nn.Module):
         self.precision = precision
         self._engine = Engine(self.cfg, dual_source=dual_source, precision=precision)
         self._prepared_fp = None
-        self._inject_cache = None
+        self._tensors = None            # flat list of parameters and buffers (rebuilt after _apply / load_state_dict)
+        self._weights_epoch = 0
 
     @classmethod
     def from_config(cls, cfg: NetConfig, dual_source: bool = True, precision=None) -> "NVPrecond":
@@ -118,17 +120,28 @@ class NVPrecond(torch.nn.Module):
                    dual_source=dual_source, precision=precision, model_channels=cfg.model_channels, channel_mult=cfg.channel_mult,
                    num_blocks=cfg.num_blocks, attn_resolutions=cfg.attn_resolutions, extra_attn=cfg.extra_attn,
                    label_balance=cfg.label_balance, concat_balance=cfg.concat_balance,
-                   res_balance=cfg.res_balance, attn_balance=cfg.attn_balance, clip_act=cfg.clip_act)
+                   res_balance=cfg.res_balance, attn_balance=cfg.attn_balance, clip_act=cfg.clip_act,
+                   channel_mult_noise=cfg.channel_mult_noise, channel_mult_emb=cfg.channel_mult_emb,
+                   resample_filter=cfg.resample_filter)
 
     # -- weights ---------------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):          # .to() / .cuda() / .float(): the tensors are replaced
+        self._tensors = None
+        self._weights_epoch += 1
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._tensors = None
+        self._weights_epoch += 1
+        return super().load_state_dict(*args, **kwargs)
+
     def _fingerprint(self):
-        fp = 0
-        first = None
-        for t in list(self.parameters()) + list(self.buffers()):
-            fp += t._version
-            if first is None:
-                first = t.data_ptr()
-        return (fp, first)
+        """Changes whenever the weights may have: an epoch bumped by load_state_dict / _apply, plus the autograd version counters
+        of the ~400 tensors (in-place edits), summed over a cached flat list instead of a walk of the module tree per call."""
+        if self._tensors is None:
+            self._tensors = list(self.parameters()) + list(self.buffers())
+        ts = self._tensors
+        return (self._weights_epoch, sum(t._version for t in ts), ts[0].data_ptr() if ts else 0)
 
     def _prepare(self, device):
         fp = self._fingerprint()
@@ -143,13 +156,14 @@ class NVPrecond(torch.nn.Module):
             params[k] = v
         self._engine.prepare_weights(params, device)
         self._prepared_fp = fp
-        self._inject_cache = None
 
     # -- forward ---------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, src, dst, sigma, geometry=None, conditioning_image=None, force_fp32=False,
                 return_logvar=False, return_features=False, inject_features=None, **unet_kwargs):
         if unet_kwargs:
+            # the reference passes these on to UNetEncoder.forward / XAttnUNet.forward (:667,:679), neither of which takes any
+            # keyword (:483,:536): there, too, any extra keyword ends in a TypeError
             raise TypeError(f"NVPrecond.forward: unexpected keywords {sorted(unet_kwargs)}")
         dev = dst.device
         if dev.type != "cuda":
@@ -210,16 +224,15 @@ class NVPrecond(torch.nn.Module):
                     cond = cond + cfg.noisy_sr * torch.randn_like(cond)                         # :658
                 put("cond", cond, (B, cfg.img_channels, R, R))
             if mode == "inject":
-                key = tuple((f.data_ptr(), f._version) for f in inject_features) + (id(prog),)
-                if key != self._inject_cache:
-                    views = prog.view("features_in")
-                    if len(views) != len(inject_features):
-                        raise ValueError(f"expected {len(views)} feature maps, got {len(inject_features)}")
-                    for v, f in zip(views, inject_features):
-                        if tuple(f.shape) != (v.shape[0], v.shape[3], v.shape[1], v.shape[2]):
-                            raise ValueError(f"feature shape {tuple(f.shape)} does not match {tuple(v.shape)} (NHWC)")
-                        v.copy_(f.permute(0, 2, 3, 1))
-                    self._inject_cache = key
+                # copied on every call, like the reference's deepcopy (:665): a cache keyed on addresses goes stale when the
+                # allocator hands a freed feature buffer's address to the next batch's features (a few MB against a whole forward)
+                views = prog.view("features_in")
+                if len(views) != len(inject_features):
+                    raise ValueError(f"expected {len(views)} feature maps, got {len(inject_features)}")
+                for v, f in zip(views, inject_features):
+                    if tuple(f.shape) != (v.shape[0], v.shape[3], v.shape[1], v.shape[2]):
+                        raise ValueError(f"feature shape {tuple(f.shape)} does not match {tuple(v.shape)} (NHWC)")
+                    v.copy_(f.permute(0, 2, 3, 1))
             prog.plan.run()
             if mode == "features":
                 # NCHW-shaped views over fresh NHWC storage (values and shapes as the reference's list)
