@@ -7,20 +7,25 @@ does per call of its `denoise` closure (generate_images.py:55-62) plus the Euler
     Dref = gnet(src, x, t)                   unconditional guidance net (UNet only)
     x'   = x + (t' - t) * (x - lerp(Dref, D, 1.5)) / t
 
-Workload (BASELINE.json configs[1]): "vivid-base UNet, 256x256, batch 16, CFG=1.5" = the base
+Headline workload (BASELINE.json configs[1]): "vivid-base UNet, 256x256, batch 16, CFG=1.5" = the base
 architecture (model_channels=128, extra_attn=1) built at img_resolution=256,
-B=16 targets = 32 dual-source rows, synthetic inputs and seeded random weights, fp32.
+B=16 targets = 32 dual-source rows, synthetic inputs and seeded random weights, fp32-grade arithmetic.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Every rank runs its own batch (independent samples shard with no data-path collective,
 generate_images.py:199-200), so scaling is weak; value = N*K steps / max-over-ranks time.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides BASELINE's metric it carries, at N = 1:
+  roofline          dominant kernel family of the timed region (HIP events on the launch stream), against both peak bases
+  parity            HIP vs the CPU oracle on one batch-1 guided evaluation of the SAME networks (the gate BASELINE.md 4 promises)
+  cpu_baseline      that oracle evaluation timed on the host cores (after one warm-up call)
+  other_workloads   short runs of the same step in exact-fp32 mode and of BASELINE configs[3] (SR net built at 1024^2, B=4) and
+                    configs[4] (base + depth-warp features at 256^2, B=16); `--no-extras` skips them
 """
 import argparse
+import gc
 import json
-import math
 import os
 import sys
 import time
@@ -33,24 +38,27 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak; bf16x3 executes 3 MFMA products per fp32 product
 PEAK_HBM_GBS = 8000.0
+EVALS_PER_IMAGE_BATCH = 63        # a 32-step Heun run = 63 denoiser evaluations (generate_images.py:74,104)
 
 WORKLOADS = {
-    # name: (img_resolution, batch, description)
-    "c2": (256, 16, "vivid-base arch @256x256, batch 16, CFG 1.5 (net + uncond gnet), dual-source"),
-    "base64": (64, 16, "vivid-base @64x64 (the reference's own base stage), batch 16, CFG 1.5"),
-    "tiny": (64, 1, "vivid-base @64x64, batch 1, CFG 1.5 (plumbing)"),
+    # name: (kind, img_resolution, batch, guided, description)
+    "c2": ("base", 256, 16, True, "vivid-base arch @256x256, batch 16, CFG 1.5 (net + uncond gnet), dual-source"),
+    "c4": ("sr", 1024, 4, False, "vivid-sr arch built @1024x1024 (256->1024), batch 4, no guidance (the SR stage has none), noisy_sr 0.25"),
+    "c5": ("warp", 256, 16, False, "vivid-base + depth-warp Fourier features @256x256, batch 16, one net evaluation (no guidance net)"),
+    "base64": ("base", 64, 16, True, "vivid-base @64x64 (the reference's own base stage), batch 16, CFG 1.5"),
+    "tiny": ("base", 64, 1, True, "vivid-base @64x64, batch 1, CFG 1.5 (plumbing)"),
 }
 
 
 def measured_traffic(precision):
-    """HBM bytes per launch per kernel family from the committed rocprofv3 PMC summary of THIS command
-    (profiles/, collected in separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md).  None when no summary for this precision is committed."""
+    """HBM bytes per launch per kernel family from a committed rocprofv3 PMC summary of THIS command (profiles/, separate --pmc
+    FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md).  NOT measured in this run:
+    the file names the build it was collected from."""
     path = os.path.join(ROOT, "profiles", f"traffic_c2_{precision}.json")
     if not os.path.exists(path):
         return {}, None
     d = json.load(open(path))
-    return {k: v["hbm_bytes_per_launch"] for k, v in d.get("families", {}).items()}, os.path.relpath(path, ROOT)
+    return {k: v["hbm_bytes_per_launch"] for k, v in d.get("families", {}).items()}, dict(file=os.path.relpath(path, ROOT), collected_from=d.get("source"))
 
 
 def rho_schedule(num_steps=32, sigma_min=0.002, sigma_max=80.0, rho=7.0):
@@ -59,38 +67,203 @@ def rho_schedule(num_steps=32, sigma_min=0.002, sigma_max=80.0, rho=7.0):
     return torch.cat([t, torch.zeros(1)])
 
 
-def make_inputs(R, B, seed, device):
+def make_inputs(R, B, seed, device, kind="base"):
     g = torch.Generator("cpu").manual_seed(seed)
-    src = (torch.rand(2 * B, 3, R, R, generator=g) * 2 - 1).to(device)
-    noise = torch.randn(B, 3, R, R, generator=g).repeat_interleave(2, dim=0).to(device)
+    src = torch.rand(2 * B, 3, R, R, generator=g) * 2 - 1
+    noise = torch.randn(B, 3, R, R, generator=g).repeat_interleave(2, dim=0)
     geo = torch.randn(2 * B, 20, generator=g)
     geo[:, [14, 15, 18, 19]] = 0
-    return src, noise, geo.to(device)
+    cond = None
+    if kind == "warp":                                   # depth U(1,5), pose from compose_geometry
+        from vivid_amd.geometry import compose_geometry
+        src = torch.cat([src, torch.rand(2 * B, 1, R, R, generator=g) * 4 + 1], dim=1)
+        th = 0.05 * torch.randn(2 * B, generator=g)
+        Rm = torch.zeros(2 * B, 3, 3)
+        Rm[:, 0, 0], Rm[:, 0, 2], Rm[:, 1, 1], Rm[:, 2, 0], Rm[:, 2, 2] = th.cos(), th.sin(), 1.0, -th.sin(), th.cos()
+        K = (torch.tensor([57.7, 57.7, 32.0, 32.0]) * (R / 64)).expand(2 * B, 4)
+        geo = compose_geometry(torch.cat([Rm, 0.1 * torch.randn(2 * B, 3, 1, generator=g)], dim=2), K, K, imsize=R)
+    if kind == "sr":                                     # bilinear-upsampled low-res image as conditioning
+        low = torch.rand(B, 3, R // 4, R // 4, generator=g) * 2 - 1
+        cond = torch.nn.functional.interpolate(low, size=(R, R), mode="bilinear", align_corners=False).to(device)
+    return src.to(device), noise.to(device), geo.to(device), cond
 
 
-def cpu_baseline(R, seconds_hint):
-    """The CPU oracle (a restatement of the reference's PyTorch-CPU path; kind="port") timed on this
-    host on a bounded sample: ONE guided evaluation at batch 1 of the same networks.  A batch-16
-    step is 16 such evaluations (cost is linear in batch), so steps/s = 1 / (16 * t_b1)."""
+def configs_for(kind, R):
+    import vivid_amd
+    if kind == "sr":
+        return vivid_amd.vivid_sr(R), None
+    if kind == "warp":
+        return vivid_amd.vivid_base(R, warp_depth_coor=True), None
+    return vivid_amd.vivid_base(R), vivid_amd.vivid_uncond(R)
+
+
+def build_nets(kind, R, precision, dev, guided):
+    import vivid_amd
+    cfg, ucfg = configs_for(kind, R)
+    net = vivid_amd.NVPrecond.from_config(cfg, precision=precision)
+    net.load_state_dict(vivid_amd.synth_state_dict(cfg, seed=0), strict=True)
+    net = net.to(dev)
+    gnet = None
+    if guided:
+        gnet = vivid_amd.NVPrecond.from_config(ucfg, precision=precision)
+        gnet.load_state_dict(vivid_amd.synth_state_dict(ucfg, seed=1), strict=True)
+        gnet = gnet.to(dev)
+    return net, gnet
+
+
+def oracle_guided_eval(R):
+    """The CPU oracle (a restatement of the reference's PyTorch-CPU path; kind="port") on a bounded sample: ONE guided evaluation at
+    batch 1 of the headline networks, run twice - an untimed warm-up (thread pools, allocator, first-touch of 1 GB of weights), then
+    the timed one.  A batch-16 step is 16 such evaluations (cost is linear in batch).  Returns the outputs too: they are the parity
+    reference for the HIP nets on the same inputs."""
     from oracle import vivid_ref as Rf
     import vivid_amd
     torch.set_grad_enabled(False)
-    cores = torch.get_num_threads()
-    cfg = vivid_amd.vivid_base(R)
-    ucfg = vivid_amd.vivid_uncond(R)
+    cfg, ucfg = vivid_amd.vivid_base(R), vivid_amd.vivid_uncond(R)
     d, ud = cfg.to_dict(), ucfg.to_dict()
     d.pop("use_fp16"); ud.pop("use_fp16")
     net = Rf.OracleNet(Rf.make_config(**d), vivid_amd.synth_state_dict(cfg, seed=0))
     gnet = Rf.OracleNet(Rf.make_config(**ud), vivid_amd.synth_state_dict(ucfg, seed=1))
-    src, noise, geo = make_inputs(R, 1, 1, "cpu")
+    src, noise, geo, _ = make_inputs(R, 1, 1, "cpu")
     t = torch.full((2,), 5.0)
     x = noise * 5.0
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        D = net(src, x, t, geo)
+        ref = gnet(src, x, t)
+        guided = ref.lerp(D, 1.5)
+        times.append(time.perf_counter() - t0)
+    return dict(seconds_b1=times[1], seconds_b1_cold=times[0], cores=torch.get_num_threads(), D=D, guided=guided,
+                inputs=(src, x, t, geo))
+
+
+def rel_l2(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / b.norm())
+
+
+def family_table(fam, steps, ms_per_step, precision):
+    kern = {}
+    for k, v in fam.items():
+        if v["launches"] == 0:
+            continue
+        s = v["ms"] / 1000.0
+        kern[k] = {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps,
+                   "tflops": v["flops"] / s / 1e12 if s > 0 else 0.0, "gbs": v["bytes"] / s / 1e9 if s > 0 else 0.0,
+                   "gflop_per_step": v["flops"] / steps / 1e9, "gbyte_per_step": v["bytes"] / steps / 1e9}
+    return kern
+
+
+def roofline_of(dom, fam, kern, ms_per_step, precision):
+    """Roofline object of one kernel family: achieved = algorithmic FLOPs (or bytes) of its launches / their summed durations."""
+    kd, vd = kern[dom], fam[dom]
+    mfma_bound = dom in ("conv3x3", "conv1x1", "attention")
+    x3 = precision == "bf16x3" and mfma_bound
+    if mfma_bound:
+        achieved, unit = kd["tflops"], "TFLOP/s"
+        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
+    else:
+        achieved, peak, unit = kd["gbs"], PEAK_HBM_GBS, "GB/s"
+    out = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": achieved, "peak": peak, "unit": unit,
+           "frac": achieved / peak, "traffic": None,
+           "algorithmic_bytes_per_launch": vd["bytes"] / vd["launches"], "avg_launch_ms": vd["ms"] / vd["launches"],
+           "launches": vd["launches"], "algorithmic_per_launch": (vd["flops"] if mfma_bound else vd["bytes"]) / vd["launches"],
+           "share_of_step": kd["ms_per_step"] / ms_per_step}
+    if mfma_bound:
+        # both readings of "peak" for fp32-grade arithmetic on gfx950 (no xf32): SURVEY 8(d) prices against the fp32 matrix peak;
+        # the bf16x3 path runs on the bf16 pipe with 3 executed products per algorithmic one
+        out["peak_basis"] = {"bf16_mfma_div3": {"peak": PEAK_BF16_MFMA_TFLOPS / 3.0, "frac": achieved / (PEAK_BF16_MFMA_TFLOPS / 3.0)},
+                             "fp32_mfma": {"peak": PEAK_FP32_MFMA_TFLOPS, "frac": achieved / PEAK_FP32_MFMA_TFLOPS},
+                             "used": "bf16_mfma_div3" if x3 else "fp32_mfma"}
+        out["note"] = ("achieved = algorithmic fp32 FLOPs/s; every fp32 product is 3 bf16 MFMA products (hi*hi+hi*lo+lo*hi, fp32 accumulate), "
+                       "so peak = 2500 TF/s dense bf16 MFMA / 3 and the executed MFMA rate is 3 x achieved" if x3 else
+                       "fp32 operands on v_mfma_f32_32x32x2_f32; peak = fp32 matrix peak (no xf32 on gfx950)")
+    return out
+
+
+def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True, batch=None, keep_nets=False):
+    """Times `steps` steps of one workload after `warmup` untimed ones; returns (result dict, (net, gnet) or None)."""
+    import vivid_amd  # noqa: F401
+    from vivid_amd.sampler import _context, _step
+    kind, R, B, guided, desc = WORKLOADS[name]
+    if batch:
+        B = batch
+    net, gnet = build_nets(kind, R, precision, dev, guided)
+    src, noise, geo, cond = make_inputs(R, B, 100 + rank, dev, kind)
+    t_steps = rho_schedule()
+    sctx = _context(dev)
+    state = {"x": (noise * float(t_steps[0])).contiguous()}
+
+    def step(i):
+        j = i % 32
+        t_hat, t_next = float(t_steps[j]), float(t_steps[j + 1])
+        x = state["x"]
+        tt = torch.full((x.shape[0],), t_hat, device=dev)
+        D = net(src, x, tt, geo, cond)
+        ref = gnet(src, x, tt) if gnet is not None else None
+        d_cur = torch.empty_like(D)
+        x_next = torch.empty_like(x)
+        _step(sctx, x, None, D, ref, 1.5 if gnet is not None else 1.0, d_cur, t_hat, t_next, x_next)
+        if j == 31:      # t_next = 0 ends a trajectory: restart from noise
+            x_next = (noise * float(t_steps[0])).contiguous()
+        state["x"] = x_next
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    ctxs = [net._engine.ctx, sctx] + ([gnet._engine.ctx] if gnet is not None else [])
+    if profile:
+        for c in ctxs:
+            c.profile_enable(True)
+    barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    D = net(src, x, t, geo)
-    ref = gnet(src, x, t)
-    _ = ref.lerp(D, 1.5)
-    dt = time.perf_counter() - t0
-    return dict(seconds_b1=dt, cores=cores)
+    for i in range(steps):
+        step(warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    fam = {}
+    if profile:
+        for c in ctxs:
+            for k, v in c.profile_read().items():
+                a = fam.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                for kk in a:
+                    a[kk] += v[kk]
+            c.profile_enable(False)
+    res = dict(name=name, desc=desc, R=R, B=B, guided=guided, precision=precision, steps=steps, warmup=warmup, elapsed=elapsed,
+               ms_per_step=1000.0 * elapsed / steps, fam=fam, finite=bool(torch.isfinite(state["x"]).all().item()),
+               params={"net": sum(p.numel() for p in net.parameters()), **({"gnet": sum(p.numel() for p in gnet.parameters())} if gnet is not None else {})})
+    if keep_nets:
+        return res, (net, gnet)
+    del net, gnet, src, noise, geo, cond, state
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res, None
+
+
+def summarise(res, world):
+    """The compact form used for the secondary workloads."""
+    out = {"workload": res["desc"], "precision": res["precision"], "dtype": "bf16x3" if res["precision"] == "bf16x3" else "f32",
+           "steps": res["steps"], "warmup": res["warmup"], "ms_per_step": res["ms_per_step"], "evals_per_s": world * res["steps"] / res["elapsed"],
+           "finite": res["finite"]}
+    if res["fam"]:
+        kern = family_table(res["fam"], res["steps"], res["ms_per_step"], res["precision"])
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        r = roofline_of(dom, res["fam"], kern, res["ms_per_step"], res["precision"])
+        out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "share_of_step")}
+        out["kernels"] = {k: {"ms_per_step": v["ms_per_step"], "tflops": v["tflops"], "gbs": v["gbs"]} for k, v in kern.items()}
+        out["whole_step_tflops"] = sum(v["flops"] for v in res["fam"].values()) / res["elapsed"] / 1e12
+    return out
 
 
 def main():
@@ -102,7 +275,8 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="override per-GPU batch (non-default runs are not the headline)")
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "fp32"],
                     help="bf16x3: fp32 emulated by a bf16 hi/lo split on bf16 MFMA (default); fp32: exact fp32 MFMA")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle leg (also drops the parity object)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads (fp32 mode, C4, C5)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing in the timed region")
     args = ap.parse_args()
 
@@ -127,139 +301,75 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import vivid_amd
-    from vivid_amd import _lib
-    from vivid_amd.sampler import _context, _step
-
-    R, B, desc = WORKLOADS[args.workload]
-    if args.batch:
-        B = args.batch
-    cfg, ucfg = vivid_amd.vivid_base(R), vivid_amd.vivid_uncond(R)
-    net = vivid_amd.NVPrecond.from_config(cfg, precision=args.precision)
-    net.load_state_dict(vivid_amd.synth_state_dict(cfg, seed=0), strict=True)
-    net = net.to(dev)
-    gnet = vivid_amd.NVPrecond.from_config(ucfg, precision=args.precision)
-    gnet.load_state_dict(vivid_amd.synth_state_dict(ucfg, seed=1), strict=True)
-    gnet = gnet.to(dev)
-    src, noise, geo = make_inputs(R, B, 100 + rank, dev)
-    t_steps = rho_schedule()
-    sctx = _context(dev)
-    state = {"x": (noise * float(t_steps[0])).contiguous()}
-
-    def step(i):
-        j = i % 32
-        t_hat, t_next = float(t_steps[j]), float(t_steps[j + 1])
-        x = state["x"]
-        tt = torch.full((x.shape[0],), t_hat, device=dev)
-        D = net(src, x, tt, geo)
-        ref = gnet(src, x, tt)
-        d_cur = torch.empty_like(D)
-        x_next = torch.empty_like(x)
-        _step(sctx, x, None, D, ref, 1.5, d_cur, t_hat, t_next, x_next)
-        if j == 31:      # t_next = 0 ends a trajectory: restart from noise
-            x_next = (noise * float(t_steps[0])).contiguous()
-        state["x"] = x_next
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-
-    ctxs = [net._engine.ctx, gnet._engine.ctx, sctx]
-    profile = not args.no_profile
-    if profile:
-        for c in ctxs:
-            c.profile_enable(True)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64,
-                            device=dev if torch.distributed.get_backend() == "nccl" else "cpu")
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    fam = {}
-    if profile:
-        for c in ctxs:
-            for k, v in c.profile_read().items():
-                a = fam.setdefault(k, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-                for kk in a:
-                    a[kk] += v[kk]
-            c.profile_enable(False)
-    finite = bool(torch.isfinite(state["x"]).all().item())
-
+    torch.set_grad_enabled(False)
+    headline = args.workload == "c2" and not args.batch
+    want_parity = world == 1 and not args.no_cpu_baseline and WORKLOADS[args.workload][0] == "base" and WORKLOADS[args.workload][3]
+    res, nets = run_workload(args.workload, args.precision, args.steps, args.warmup, dev, rank, world, profile=not args.no_profile,
+                             batch=args.batch, keep_nets=want_parity)
+    R, B = res["R"], res["B"]
+    out = None
     if rank == 0:
+        evals_per_s = world * args.steps / res["elapsed"]
         out = {
-            "metric": "denoise-steps/sec", "value": world * args.steps / elapsed,
+            "metric": "denoise-steps/sec", "value": evals_per_s,
             "unit": f"guided denoiser evaluations/s (batch {B} per GPU, {R}x{R})",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16x3" if args.precision == "bf16x3" else "f32", "data": "synthetic",
-            "config": {"workload": desc, "img_resolution": R, "batch_per_gpu": B, "guidance": 1.5, "precision": args.precision,
-                       "global_batch": B * world, "parallelism": f"dp{world} (independent samples per rank, no collective)",
-                       "params": {"net": sum(p.numel() for p in net.parameters()), "gnet": sum(p.numel() for p in gnet.parameters())}},
-            "finite": finite,
+            "config": {"workload": res["desc"], "img_resolution": R, "batch_per_gpu": B, "guidance": 1.5 if res["guided"] else 1.0,
+                       "precision": args.precision, "global_batch": B * world,
+                       "parallelism": f"dp{world} (independent samples per rank, no collective)", "params": res["params"]},
+            # denoise-steps/sec := denoiser evaluations/s; a 32-step Heun sampler run makes 63 of them per image batch
+            "sampler_steps_per_s": evals_per_s / EVALS_PER_IMAGE_BATCH * 32,
+            "images_per_s": evals_per_s / EVALS_PER_IMAGE_BATCH * B,
+            "finite": res["finite"],
         }
+        fam = res["fam"]
         if fam:
-            steps = args.steps
-            kern = {}
-            for k, v in fam.items():
-                if v["launches"] == 0:
-                    continue
-                s = v["ms"] / 1000.0
-                kern[k] = {"ms_per_step": v["ms"] / steps, "launches_per_step": v["launches"] / steps,
-                           "tflops": v["flops"] / s / 1e12 if s > 0 else 0.0, "gbs": v["bytes"] / s / 1e9 if s > 0 else 0.0,
-                           "gflop_per_step": v["flops"] / steps / 1e9, "gbyte_per_step": v["bytes"] / steps / 1e9}
+            kern = family_table(fam, args.steps, res["ms_per_step"], args.precision)
             dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
-            kd, vd = kern[dom], fam[dom]
-            mfma_bound = dom in ("conv3x3", "conv1x1", "attention")
-            x3 = args.precision == "bf16x3" and dom in ("conv3x3", "attention")
-            if mfma_bound:
-                achieved, unit = kd["tflops"], "TFLOP/s"
-                peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if x3 else PEAK_FP32_MFMA_TFLOPS
-            else:
-                achieved, peak, unit = kd["gbs"], PEAK_HBM_GBS, "GB/s"
-            traffic, tsrc = measured_traffic(args.precision) if args.workload == "c2" and not args.batch else ({}, None)
-            out["roofline"] = {"kernel": dom, "bound": "mfma" if mfma_bound else "hbm", "achieved": achieved, "peak": peak,
-                               "unit": unit, "frac": achieved / peak, "traffic": traffic.get(dom), "traffic_source": tsrc,
-                               "algorithmic_bytes_per_launch": vd["bytes"] / vd["launches"],
-                               "avg_launch_ms": vd["ms"] / vd["launches"], "launches": vd["launches"],
-                               "algorithmic_per_launch": (vd["flops"] if mfma_bound else vd["bytes"]) / vd["launches"],
-                               "share_of_step": kd["ms_per_step"] / out["ms_per_step"],
-                               "note": ("achieved = algorithmic fp32 FLOPs/s; every fp32 product is 3 bf16 MFMA products (hi*hi+hi*lo+lo*hi, "
-                                        "fp32 accumulate), so peak = 2500 TF/s dense bf16 MFMA / 3; executed MFMA rate = 3 x achieved"
-                                        if x3 else "fp32 operands on v_mfma_f32_32x32x2_f32; peak = fp32 matrix peak (no xf32 on gfx950)")}
+            out["roofline"] = roofline_of(dom, fam, kern, res["ms_per_step"], args.precision)
+            traffic, tsrc = measured_traffic(args.precision) if headline else ({}, None)
             tr = traffic.get(dom)
-            if tr is not None:                              # measured HBM stream of the same kernel: bytes per launch / launch time
-                out["roofline"]["hbm_gbs"] = tr / (vd["ms"] / vd["launches"] / 1e3) / 1e9
-                out["roofline"]["hbm_frac"] = out["roofline"]["hbm_gbs"] / PEAK_HBM_GBS
-            # north_star also asks for the attention kernels' MFMA utilisation: same definition, second family
-            if "attention" in kern and dom != "attention":
-                ka, va = kern["attention"], fam["attention"]
-                pk = PEAK_BF16_MFMA_TFLOPS / 3.0 if args.precision == "bf16x3" else PEAK_FP32_MFMA_TFLOPS
-                out["roofline_attention"] = {"bound": "mfma", "achieved": ka["tflops"], "peak": pk, "unit": "TFLOP/s",
-                                             "frac": ka["tflops"] / pk, "avg_launch_ms": va["ms"] / va["launches"],
-                                             "traffic": traffic.get("attention"), "share_of_step": ka["ms_per_step"] / out["ms_per_step"]}
-            from vivid_amd import engine as _eng
-            out["config"]["conv_stagger_autotuned"] = {str(k): v for k, v in _eng._TUNED.items()}   # per device: 1 = staggered DMA issue won the start-up A/B
+            if tr is not None:
+                # bytes per launch come from a committed PMC profile (not from this run); the rate divides them by THIS run's launch time
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_source"] = dict(tsrc, measured_in_this_run=False)
+                out["roofline"]["traffic_over_algorithmic"] = tr / out["roofline"]["algorithmic_bytes_per_launch"]
+                out["roofline"]["hbm_gbs_from_profile_bytes"] = tr / (out["roofline"]["avg_launch_ms"] / 1e3) / 1e9
+            if "attention" in kern and dom != "attention":       # north_star also asks for the attention kernels' MFMA utilisation
+                out["roofline_attention"] = roofline_of("attention", fam, kern, res["ms_per_step"], args.precision)
+                out["roofline_attention"]["traffic"] = traffic.get("attention")
             out["kernels"] = kern
-            tot_fl = sum(v["flops"] for v in fam.values())
-            out["whole_step_tflops"] = tot_fl / elapsed / 1e12
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(R, 30)
-            out["cpu_baseline"] = {"value": 1.0 / (B * cb["seconds_b1"]), "unit": out["unit"], "cores": cb["cores"],
-                                   "kind": "port",
-                                   "sample": f"one guided evaluation (net + uncond gnet) of the same {R}x{R} networks at batch 1 on the "
-                                             f"CPU oracle took {cb['seconds_b1']:.2f} s; a batch-{B} step is {B} of them (cost linear in batch)"}
+            out["whole_step_tflops"] = sum(v["flops"] for v in fam.values()) / res["elapsed"] / 1e12
+
+    if want_parity and rank == 0:
+        # CPU oracle on one batch-1 guided evaluation: the reported CPU baseline AND the parity reference for the HIP nets
+        net, gnet = nets
+        cb = oracle_guided_eval(R)
+        src, x, t, geo = (v.to(dev) for v in cb["inputs"])
+        D = net(src, x, t, geo)
+        Dg = gnet(src, x, t)
+        guided = Dg.lerp(D, 1.5)
+        out["parity"] = {"rel_l2_D": rel_l2(D.cpu(), cb["D"]), "rel_l2_guided": rel_l2(guided.cpu(), cb["guided"]), "tolerance": 1e-3,
+                         "against": "oracle/vivid_ref.py (CPU, fp32) on the same weights and inputs, batch 1, sigma 5, guidance 1.5",
+                         "pass": bool(rel_l2(guided.cpu(), cb["guided"]) < 1e-3)}
+        out["cpu_baseline"] = {"value": 1.0 / (B * cb["seconds_b1"]), "unit": out["unit"], "cores": cb["cores"], "kind": "port",
+                               "sample": f"one guided evaluation (net + uncond gnet) of the same {R}x{R} networks at batch 1 on the CPU oracle "
+                                         f"took {cb['seconds_b1']:.2f} s after one untimed warm-up call ({cb['seconds_b1_cold']:.2f} s cold); "
+                                         f"a batch-{B} step is {B} of them (cost linear in batch)"}
+    nets = None
+    gc.collect()
+    torch.cuda.empty_cache()
+
+    if world == 1 and headline and not args.no_extras and rank == 0:
+        extras = {}
+        for key, (wl, prec, k, w) in {"c2_fp32": ("c2", "fp32", 2, 1), "c4_sr1024_b4": ("c4", "bf16x3", 3, 1),
+                                      "c5_warp256_b16": ("c5", "bf16x3", 3, 1)}.items():
+            r2, _ = run_workload(wl, prec, k, w, dev, rank, world, profile=not args.no_profile)
+            extras[key] = summarise(r2, world)
+        out["other_workloads"] = extras
+    if rank == 0:
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

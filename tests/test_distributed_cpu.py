@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: the seed-sharding rule and the fp64 moment all_reduce."""
+"""CPU, world_size 2 over gloo: the seed-sharding rule and the one-bucket fp64 moment all_reduce."""
 import os
 import socket
 
@@ -25,17 +25,19 @@ def _worker(rank, world, port, n_seeds, max_batch, out_dir):
         batches = vd.rank_batches(n_seeds, max_batch)
         g = torch.Generator().manual_seed(5)
         feats_all = torch.randn(n_seeds, 8, generator=g)          # "feature of seed i" — same on every rank
-        st = vd.MomentStats(8)
+        from vivid_amd.metrics import MomentBank
+        bank = MomentBank({"f": 8}, (), "cpu", allow_host=True)     # CPU rehearsal bank: the reduce is what is under test
         for b in batches:
             if len(b):
-                st.append(feats_all[torch.as_tensor(b)])
+                f = feats_all[torch.as_tensor(b)]
+                bank.add_features("f", f, f)
+                bank.add_counts(len(b), len(b))
             torch.distributed.barrier()                           # one barrier per batch (generate_images.py:340)
-        st.all_reduce()
-        mu, cov = st.mean_cov()
+        gen, _ = bank.all_reduce().finalize(False)               # ONE all_reduce of the whole bank
         t = torch.tensor([1.0 + rank], dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)   # bench.py's max-over-ranks timing
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), idx=np.concatenate(batches) if batches else np.zeros(0),
-                 mu=mu.numpy(), cov=cov.numpy(), n=int(st.n), tmax=float(t))
+                 mu=gen["f"]["mu"], cov=gen["f"]["sigma"], n=gen["num_images"], tmax=float(t))
     finally:
         torch.distributed.destroy_process_group()
 
@@ -121,3 +123,33 @@ def test_fid_stats_two_ranks_equal_one_rank(tmp_path):
     # identical statistics give distance 0
     z = vm.calculate_metrics_from_stats_nvs(r.stats, r.stats, metrics=["fid"])
     assert abs(z["fid"]) < 1e-8
+
+
+def test_bank_is_strict_about_its_device():
+    from vivid_amd import metrics as vm
+    with pytest.raises(RuntimeError, match="allow_host"):
+        vm.MomentBank({"fid": 4}, (), "cpu")
+
+
+def test_joint_blocks_equal_the_reference_formulation():
+    """The five-block bank against calculate_metrics.py:158-182 restated with numpy: moments of cat([f, fs]) computed whole."""
+    from vivid_amd import metrics as vm
+    g = torch.Generator().manual_seed(9)
+    F, n = 5, 11
+    fg, ft, fs = (torch.randn(n, F, generator=g) for _ in range(3))
+    bank = vm.MomentBank({"fid": F}, ("fid",), "cpu", allow_host=True)
+    for lo, hi in ((0, 4), (4, 11)):
+        bank.add_features("fid", fg[lo:hi], ft[lo:hi], fs[lo:hi])
+        bank.add_counts(hi - lo, hi - lo)
+    gen, ref = bank.finalize(False)
+    for side, f in ((gen, fg), (ref, ft)):
+        j = torch.cat([f, fs], -1).double().numpy()
+        mu = j.sum(0) / n
+        sigma = (j.T @ j - np.outer(mu, mu) * n) / (n - 1)
+        np.testing.assert_allclose(side["joint_fid"]["mu"], mu, rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(side["joint_fid"]["sigma"], sigma, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(side["fid"]["sigma"], sigma[:F, :F], rtol=1e-12, atol=1e-13)
+    # closed form: two Gaussians with commuting covariances, d = |dmu|^2 + sum (sqrt(a) - sqrt(b))^2
+    a, b = np.array([1.0, 4.0, 9.0]), np.array([4.0, 1.0, 16.0])
+    d = vm.frechet_distance(np.zeros(3), np.diag(a), np.array([1.0, 2.0, 2.0]), np.diag(b))
+    assert abs(d - (9.0 + ((np.sqrt(a) - np.sqrt(b)) ** 2).sum())) < 1e-9

@@ -110,6 +110,58 @@ def test_inputs_not_mutated_and_fresh_output():
         assert torch.equal(a, b)
 
 
+def test_injected_features_are_read_on_every_call():
+    """A freed feature list's addresses may be handed to the next batch's features by the caching allocator: the injected
+    maps must be read on each call, never recognised by address (the sampler's no_time_enc path, generate_images.py:52-57)."""
+    case = CASES["tiny_nte"]
+    net = _net(case["cfg"], case["seed"])
+    inp = _cuda(make_inputs(case))
+    sig = torch.full((inp["src"].shape[0],), 1.5, device="cuda")
+    x = x_for(inp, 1.5)
+    one = torch.ones_like(sig)
+    fa = net(inp["src"], torch.zeros_like(inp["src"]), one, inp["geometry"], return_features=True)
+    da = net(inp["src"], x, sig, inp["geometry"], inject_features=fa)
+    ptrs = [f.data_ptr() for f in fa]
+    src_b = inp["src"].flip(0).contiguous() * 0.5
+    want = net(src_b, x, sig, inp["geometry"])                   # encoder run inside the call (no_time_enc nets ignore sigma there)
+    del fa
+    fb = net(src_b, torch.zeros_like(src_b), one, inp["geometry"], return_features=True)
+    reused = sum(p == f.data_ptr() for p, f in zip(ptrs, fb))
+    db = net(src_b, x, sig, inp["geometry"], inject_features=fb)
+    assert rel_l2(db.cpu(), want.cpu()) < 1e-6, f"stale injected features ({reused} buffers came back at the same address)"
+    assert rel_l2(db.cpu(), da.cpu()) > 1e-3
+    # and an in-place edit of a live list is seen as well
+    for f in fb:
+        f.zero_()
+    dz = net(src_b, x, sig, inp["geometry"], inject_features=fb)
+    assert rel_l2(dz.cpu(), db.cpu()) > 1e-3
+
+
+def test_failed_op_leaves_the_engine_usable():
+    """An op refused while a plan is being recorded must not leave the context in recording mode (the next forward would
+    fail with 'already recording' and hide the real error)."""
+    import vivid_amd
+    from vivid_amd import _lib
+    case = CASES["tiny_dual"]
+    net = _net(case["cfg"], case["seed"])
+    inp = _cuda(make_inputs(case))
+    sig = torch.full((inp["src"].shape[0],), 2.0, device="cuda")
+    eng = net._engine
+    net._prepare(torch.device("cuda", torch.cuda.current_device()))
+    real = eng._assemble
+
+    def broken(*a, **k):
+        if eng._emit:                                            # fail in the recording pass, after vh_plan_begin
+            raise _lib.VividHipError("injected failure")
+        return real(*a, **k)
+    eng._assemble = broken
+    with pytest.raises(_lib.VividHipError, match="injected failure"):
+        net(inp["src"], x_for(inp, 2.0), sig, inp["geometry"])
+    eng._assemble = real
+    D = net(inp["src"], x_for(inp, 2.0), sig, inp["geometry"])
+    assert torch.isfinite(D).all()
+
+
 def test_cpu_input_fails_loudly():
     case = CASES["tiny_dual"]
     net = _net(case["cfg"], case["seed"])

@@ -73,6 +73,31 @@ def test_vivid_sr_256_vs_oracle():
     assert rel_l2(D.cpu(), ref) < 1e-4
 
 
+def test_headline_config_vs_oracle_batch1():
+    """BASELINE configs[1] - the workload bench.py times: base architecture built at 256x256 with its unconditional guidance net,
+    one guided evaluation `ref.lerp(D, 1.5)` (generate_images.py:55-62) - HIP (bf16x3, the benchmark's precision) against the CPU
+    oracle DIRECTLY, at batch 1 (the oracle needs about a minute on the GPU box's host cores; it is linear in batch).  This is the
+    path through the 16384 x 49152 cross-attention, the 256x256-level convolutions and the closed-form zero keys."""
+    import vivid_amd
+    cfg, ucfg = vivid_amd.vivid_base(256), vivid_amd.vivid_uncond(256)
+    net, sd = _net(cfg, 0, "bf16x3")
+    gnet, usd = _net(ucfg, 1, "bf16x3")
+    src, img, eps, geo = _inputs(256, 1, 21)
+    sigma = 5.0
+    x = img + sigma * eps
+    sig = torch.full((2,), sigma)
+    D = net(src.cuda(), x.cuda(), sig.cuda(), geo.cuda())
+    Dg = gnet(src.cuda(), x.cuda(), sig.cuda())
+    guided = Dg.lerp(D, 1.5).cpu()
+    with torch.no_grad():
+        rD = R.nvprecond_forward(sd, _ocfg(cfg), src, x, sig, geo)
+        rG = R.nvprecond_forward(usd, _ocfg(ucfg), src, x, sig, None)
+    assert D.shape == rD.shape == (1, 3, 256, 256)
+    assert rel_l2(D.cpu(), rD) < 1e-4
+    assert rel_l2(Dg.cpu(), rG) < 1e-4
+    assert rel_l2(guided, rG.lerp(rD, 1.5)) < 1e-4
+
+
 def test_base_256_kernel_families_agree_and_samples_independent():
     import vivid_amd
     cfg = vivid_amd.vivid_base(256)

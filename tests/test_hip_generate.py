@@ -85,14 +85,55 @@ def test_driver_matches_oracle_pipeline_and_is_seed_deterministic(tmp_path):
     assert int((ia - ib).abs().max()) <= 1
 
 
-def test_sr_cascade_runs():
+def _mk_sr(cfg, seed):
+    """SR net with the conditioning noise switched off (the reference draws randn inside forward, training/models.py:658)."""
+    import vivid_amd
+    cfg0 = cfg.__class__(**{**cfg.to_dict(), "noisy_sr": 0.0})
+    net = vivid_amd.NVPrecond.from_config(cfg0)
+    net.load_state_dict(vivid_amd.synth_state_dict(cfg, seed=seed))
+    return net.cuda()
+
+
+def test_sr_cascade_matches_oracle_pipeline():
+    """generate_images.py:310-327: base sampler -> bilinear (anti-aliased) resize of the LATENTS to the SR resolution -> second
+    edm_sampler with gnet = sr_model and the low-res latents as conditioning image -> decode.  Oracle pipeline on the same batch
+    and seeds: oracle samplers + F.interpolate(antialias=True), which is what torchvision's resize calls for tensors."""
+    import vivid_amd
     from vivid_amd.generate import generate_images_nvs
-    base = _mk(CASES["tiny_dual"]["cfg"], 3)
-    sr_cfg = CASES["tiny_sr"]["cfg"]
-    sr = _mk(sr_cfg, 9)
-    out = list(generate_images_nvs(base, seeds=[16, 17], max_batch_size=2, data=_data(4, 16, 3), sr_model=sr, num_steps=2))
+    bcfg, scfg = CASES["tiny_dual"]["cfg"], CASES["tiny_sr"]["cfg"]
+    base, sr = _mk(bcfg, 3), _mk_sr(scfg, 9)
+    seeds = [16, 17]
+    out = list(generate_images_nvs(base, seeds=seeds, max_batch_size=2, data=_data(4, 16, 3), sr_model=sr, num_steps=2, rng_device="cpu"))
     assert out[0].images.shape == (2, 3, 32, 32) and out[0].images.dtype == torch.uint8
-    assert out[0].noise.shape == (4, 3, 32, 32)
+    assert out[0].noise.shape == (4, 3, 32, 32) and out[0].src.shape == (2, 3, 32, 32)
+    batch = next(_data(4, 16, 3))
+    rep = lambda t: t.repeat_interleave(2, dim=0)      # noqa: E731
+    pick = lambda k: batch[k][::2][:2]                 # noqa: E731
+    d = bcfg.to_dict(); d.pop("use_fp16")
+    sd_ = scfg.to_dict(); sd_.pop("use_fp16"); sd_["noisy_sr"] = 0.0
+    obase = R.OracleNet(R.make_config(**d), vivid_amd.synth_state_dict(bcfg, seed=3))
+    osr = R.OracleNet(R.make_config(**sd_), vivid_amd.synth_state_dict(scfg, seed=9))
+    noise = rep(R.StackedRandomGenerator("cpu", seeds).randn([2, 3, 16, 16]))
+    lat = R.edm_sampler(obase, rep(R.encode_latents(pick("src_image"))), noise, labels=rep(pick("geometry")), gnet=obase, num_steps=2)
+    low = torch.nn.functional.interpolate(lat, size=(32, 32), mode="bilinear", align_corners=False, antialias=True)
+    sr_noise = rep(R.StackedRandomGenerator("cpu", seeds).randn([2, 3, 32, 32]))
+    sr_lat = R.edm_sampler(osr, rep(R.encode_latents(pick("sr_src_image"))), sr_noise, labels=rep(pick("sr_geometry")), gnet=osr,
+                           conditioning_image=low, num_steps=2)
+    ref = R.decode_latents(sr_lat)
+    diff = (out[0].images.cpu().int() - ref.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.01
+
+
+def test_sr_handoff_downscale_matches_antialiased_interpolate():
+    """The other resize of the cascade (:299-302): the SR net's conditioning image is the target shrunk 4x with the triangle
+    filter widened to the scale (torchvision resize(antialias) on tensors = aten upsample_bilinear2d_aa) and blown up again."""
+    from vivid_amd.generate import resize
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    f = torch.nn.functional.interpolate
+    ref = f(f(x, size=(16, 16), mode="bilinear", antialias=True), size=(64, 64), mode="bilinear", antialias=True)
+    got = resize(resize(x.cuda(), 16), 64)
+    assert rel_l2(got.cpu(), ref) < 1e-6
 
 
 def test_urls_are_refused():
@@ -158,6 +199,23 @@ def _write_snapshot_like(path, cfg, sd):
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_snapshot_codec_is_taken_from_the_file(tmp_path):
+    """generate_images.py:170-173: encoder=None means the snapshot's own codec; one this build does not have must raise instead of
+    being replaced by the RGB codec."""
+    import pickle
+    import vivid_amd
+    from vivid_amd.generate import generate_images_nvs
+    from vivid_amd import snapshot
+    cfg = CASES["tiny_dual"]["cfg"]
+    path = str(tmp_path / "network-snapshot-0000002.pkl")
+    _write_snapshot_like(path, cfg, vivid_amd.synth_state_dict(cfg, seed=3))
+    data = snapshot.read_snapshot(path)
+    assert isinstance(snapshot.snapshot_encoder(data), vivid_amd.StandardRGBEncoder)
+    data["encoder"] = snapshot.SnapshotNet("StabilityVAEEncoder", {})
+    with pytest.raises(TypeError, match="unsupported encoder"):
+        snapshot.snapshot_encoder(data)
 
 
 def test_driver_accepts_snapshot_paths(tmp_path):

@@ -161,6 +161,53 @@ def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
     assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
 
 
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("korder", [1, 2])                  # VH_KORDER_TAP, VH_KORDER_CHUNK
+@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64
+def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
+    """Every workgroup tile of conv_x3_glds with both K orders and every epilogue, forced through vh_conv_args.tile / .korder on a
+    small ragged problem, against the oracle's mp_conv (the wide tile with chunk-major K is what the headline 128x128 layers run;
+    the size rule alone would never pick it below 150 MB of input).  fp32 and S8 outputs are both checked."""
+    from vivid_amd import _lib as L
+    rows, h, w, cin = 2, 24, 20, 96                           # M = 960: a partial 256- and 512-row tile; 3 channel chunks x 9 taps
+    g = torch.Generator().manual_seed(tile * 100 + cout + korder * 10 + epi)
+    x = torch.randn(rows, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g)
+    y = R.mp_conv(x, wgt, gain=1.0)
+    cvec = torch.randn(rows, cout, generator=g) * 0.3 + 1
+    res = torch.randn(rows, cout, h, w, generator=g)
+    ta, tb, clip = 0.7, 0.3, 2.5
+    ref = R.mp_silu(y * cvec[:, :, None, None]) if epi == 1 else (res * ta + y * tb).clip(-clip, clip) if epi == 2 else y
+    M = rows * h * w
+    xd = _nhwc(x).cuda()
+    xs8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+    out = torch.full((M, cout), float("nan"), device="cuda")
+    o8 = torch.empty(M * cout, device="cuda") if cout % 32 == 0 else None
+    cd, rd = cvec.cuda().contiguous(), _nhwc(res).cuda()
+    ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                  taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                  scratch=None, scratch_floats=0, cout=cout, out=out.data_ptr(),
+                                  out_s8=o8.data_ptr() if o8 is not None else None, out_s8_c=cout if o8 is not None else 0,
+                                  prec=1, kernel=1, epi=epi, cvec=cd.data_ptr() if epi == 1 else None, cvec_ld=cout if epi == 1 else 0,
+                                  res=rd.data_ptr() if epi == 2 else None, res_up=0, ta=ta, tb=tb, clip=clip if epi == 2 else 0,
+                                  korder=korder, tile=tile))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
+    if o8 is not None:
+        assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5
+
+
+def test_conv_forced_tile_is_validated(ctx):
+    from vivid_amd import _lib as L
+    with pytest.raises(L.VividHipError, match="256x256"):
+        ctx.call("vh_conv", L.ConvArgs(src0=_zeros(), src1=None, c0=32, c1=0, scale0=1.0, scale1=1.0, rows=1, h=8, w=8, up=0, taps=9, pro=0,
+                                      wt=_zeros(), cin_pad=32, k_pad=288, zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0,
+                                      cout=96, out=_zeros(), out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=0, tile=2))
+
+
 @pytest.mark.parametrize("rows,h,w,cin,cout", [(2, 64, 64, 128, 256), (1, 128, 128, 64, 128), (4, 32, 32, 256, 384)])
 def test_conv_stagger_hint_does_not_change_results(ctx, rows, h, w, cin, cout):
     """vh_conv_args.stagger is a scheduling hint (which wave issues its DMA when): outputs are bit-identical."""
@@ -269,6 +316,9 @@ def test_pixnorm_and_s8(ctx, pool):
     assert rel_l2(_s8_decode(s8, (rows, h, w, c)).cpu(), _nhwc(R.mp_silu(ref))) < 2e-5
 
 
+# the last two: one (batch, head) slice of the headline workload's 128x128-level attention - S = 16384 queries against
+# 49152 keys (self + two source views) in the net, against 16384 keys + 32768 closed-form zero keys in the guidance net
+ATT_BIG = [(1, 1, 16384, 49152, 64, 0), (1, 1, 16384, 16384, 64, 32768)]
 ATT_CASES = [(1, 1, 4, 8, 64, 0), (2, 2, 4, 12, 64, 0), (1, 3, 16, 32, 64, 0), (2, 1, 16, 48, 32, 0), (1, 2, 64, 192, 64, 0),
              (1, 2, 256, 768, 64, 0), (1, 1, 300, 300, 32, 0), (2, 2, 64, 64, 64, 128), (1, 4, 1024, 1024, 32, 0),
              (1, 1, 130, 200, 64, 5), (1, 2, 200, 333, 64, 77), (1, 1, 256, 512, 64, 512)]
@@ -380,6 +430,13 @@ def test_conv_qkv_epilogue_matches_split_kernel(ctx, rows, nsrc, hw, heads, cin,
             da = _s8_like_decode(a_, name, b * heads, klp, D)
             db = _s8_like_decode(b_, name, b * heads, klp, D)
             assert torch.isfinite(db).all() and rel_l2(db, da) < 2e-6, (nj, name)
+
+
+@pytest.mark.parametrize("b,heads,s,kl,d,nz", ATT_BIG)
+def test_attention_headline_slice_vs_sdpa(ctx, b, heads, s, kl, d, nz):
+    """attn_fwd_bf16x3_pipe at the sequence lengths the benchmark runs (40 % of its step), as the engine calls it (bounded
+    logits -> no running maximum), against F.scaled_dot_product_attention on the CPU in fp32."""
+    test_qkv_split_and_attention(ctx, 2, b, heads, s, kl, d, nz)
 
 
 def _s8_like_decode(buf, which, bh, klp, D):
@@ -507,3 +564,77 @@ def test_codec_and_add_depth():
     assert rel_l2(got.cpu(), ref) < 1e-6
     got2 = vivid_amd.add_depth(depth.cuda(), src.cuda(), inv_norm=False)
     assert torch.equal(got2.cpu(), torch.cat([src, depth], dim=1))
+
+
+@pytest.mark.parametrize("up", [0, 1])
+@pytest.mark.parametrize("f", [(1.0, 3.0, 3.0, 1.0), (1.0, 1.0), (1.0, 2.0, 4.0, 4.0, 2.0, 1.0)])
+def test_resample_general_filter(ctx, up, f):
+    """vh_resample against the reference's depthwise (transposed) convolution (training/models.py:48-61; an asymmetric-free but
+    non-trivial 6-tap filter too)."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(len(f) + up)
+    rows, c, h, w = 2, 24, 10, 6
+    x = torch.randn(rows, c, h, w, generator=g)
+    f1 = torch.tensor(f) / sum(f)
+    pad = (len(f) - 1) // 2
+    k = torch.outer(f1, f1)[None, None].tile([c, 1, 1, 1])
+    ref = torch.nn.functional.conv_transpose2d(x, k * 4, groups=c, stride=2, padding=pad) if up else \
+        torch.nn.functional.conv2d(x, k, groups=c, stride=2, padding=pad)
+    assert rel_l2(R.resample(x, "up" if up else "down", f), ref) < 1e-6        # the oracle's own statement (incl. its [1,1] shortcut)
+    xd = _nhwc(x).cuda()
+    out = torch.empty(rows, ref.shape[2], ref.shape[3], c, device="cuda")
+    a = L.ResampleArgs(inp=xd.data_ptr(), out=out.data_ptr(), rows=rows, h=h, w=w, c=c, up=up, ntaps=len(f))
+    for i, v in enumerate(f1.tolist()):
+        a.taps[i] = v
+    ctx.call("vh_resample", a)
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu(), _nhwc(ref)) < 1e-6
+
+
+def test_nonzero_flag(ctx):
+    from vivid_amd import _lib as L
+    x = torch.zeros(3, 4, 8, 8)
+    x[:, 3] = 2.0                                             # the depth channel does not count (c_used = 3)
+    flag = torch.full((1,), 7.0, device="cuda")
+    for poke, want in ((None, 0.0), ((2, 1, 5, 5), 1.0)):
+        if poke:
+            x[poke] = -1e-30
+        xd = x.cuda()
+        ctx.call("vh_nonzero_flag", L.NonzeroArgs(inp=xd.data_ptr(), rows=3, c_used=3, c_total=4, hw=64, flag=flag.data_ptr()))
+        torch.cuda.synchronize()
+        assert float(flag) == want
+
+
+@pytest.mark.parametrize("n,fa,fb", [(5, 48, 48), (16, 130, 70), (37, 64, 256)])
+def test_moments_fp64(ctx, n, fa, fb):
+    """vh_moments (v_mfma_f64_16x16x4_f64) against numpy fp64: features.T @ features and cross blocks, accumulated over two calls."""
+    import numpy as np
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(n + fa)
+    outer = torch.zeros(fa, fb, dtype=torch.float64, device="cuda")
+    ssum = torch.zeros(fa, dtype=torch.float64, device="cuda")
+    want_o, want_s = np.zeros((fa, fb)), np.zeros(fa)
+    for _ in range(2):
+        A = torch.randn(n, fa, generator=g) * 3 + 1
+        B = A if fa == fb else torch.randn(n, fb, generator=g)
+        Ad, Bd = A.cuda(), B.cuda()
+        ctx.call("vh_moments", L.MomentsArgs(a=Ad.data_ptr(), b=Bd.data_ptr(), n=n, fa=fa, fb=fb, outer=outer.data_ptr(), sum_a=ssum.data_ptr()))
+        torch.cuda.synchronize()
+        want_o += A.double().numpy().T @ B.double().numpy()
+        want_s += A.double().numpy().sum(0)
+    assert np.abs(outer.cpu().numpy() - want_o).max() <= 1e-12 * np.abs(want_o).max()
+    assert np.abs(ssum.cpu().numpy() - want_s).max() <= 1e-12 * np.abs(want_s).max()
+
+
+def test_psnr_sum(ctx):
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, 256, (3, 3, 16, 16), generator=g, dtype=torch.uint8)
+    y = torch.randint(0, 256, (3, 3, 16, 16), generator=g, dtype=torch.uint8)
+    want = float((10 * torch.log10(255 ** 2 / ((x.float() - y.float()) ** 2).mean((1, 2, 3)))).double().sum())
+    for dt, conv in ((0, lambda t: t.cuda()), (1, lambda t: t.float().cuda())):
+        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+        xd, yd = conv(x), conv(y)
+        ctx.call("vh_psnr_sum", L.PsnrArgs(x=xd.data_ptr(), y=yd.data_ptr(), images=3, elems=3 * 16 * 16, dtype=dt, acc=acc.data_ptr()))
+        torch.cuda.synchronize()
+        assert abs(float(acc) - want) < 1e-5 * abs(want)

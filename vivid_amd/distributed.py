@@ -4,8 +4,9 @@ The sampler has no data-path collective: independent seeds are split across rank
 reference's driver does (``generate_images.py:199-200``) and a sample's noise is a function of its
 seed only (``StackedRandomGenerator``, :120-134), so results do not depend on placement.  The only
 real exchange on the reference's north-star path is the end-of-run all_reduce(SUM) of fp64 feature
-moments in ``calculate_metrics.py:176-182,236`` (not an all-gather); :class:`MomentStats` restates
-that accumulator.  Rendezvous follows ``torch_utils/distributed.py:23-48`` (env://).
+moments in ``calculate_metrics.py:176-182,236`` (not an all-gather): ``vivid_amd.metrics.MomentBank``
+keeps them in one flat buffer and reduces it with one collective.  Rendezvous follows
+``torch_utils/distributed.py:23-48`` (env://).
 """
 from __future__ import annotations
 
@@ -48,31 +49,3 @@ def rank_batches(num_seeds: int, max_batch_size: int, world_size: Optional[int] 
     r = get_rank() if rank is None else rank
     num_batches = max((num_seeds - 1) // (max_batch_size * W) + 1, 1) * W
     return np.array_split(np.arange(num_seeds), num_batches)[r::W]
-
-
-class MomentStats:
-    """fp64 first and second moments of feature rows with an all_reduce(SUM) at the end
-    (FeatureStats-style accumulation of calculate_metrics.py:176-182; the reduce of :236)."""
-
-    def __init__(self, num_features: int, device="cpu"):
-        self.n = torch.zeros([], dtype=torch.int64, device=device)
-        self.sum = torch.zeros(num_features, dtype=torch.float64, device=device)
-        self.outer = torch.zeros(num_features, num_features, dtype=torch.float64, device=device)
-
-    def append(self, feats: torch.Tensor):
-        f = feats.to(torch.float64)
-        self.n += f.shape[0]
-        self.sum += f.sum(0)
-        self.outer += f.T @ f
-
-    def all_reduce(self):
-        if torch.distributed.is_initialized() and get_world_size() > 1:
-            for t in (self.n, self.sum, self.outer):
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
-        return self
-
-    def mean_cov(self):
-        n = float(self.n)
-        mu = self.sum / n
-        sigma = (self.outer - torch.outer(mu, self.sum)) / (n - 1)
-        return mu, sigma

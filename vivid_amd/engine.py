@@ -124,7 +124,7 @@ class Engine:
         # replay each recorded evaluation as one hipGraph: measured null on MI355X (15.1 vs 15.2 ms at batch 1, 376.7 vs
         # 377.4 ms at the headline workload: replay is GPU-bound, not launch-bound), so opt-in only
         self.use_graph = os.environ.get("VIVID_HIPGRAPH", "0") == "1"
-        self.conv_stagger = 0                 # vh_conv scheduling hint, set by _autotune_conv() once the device is known
+        self.conv_stagger = 0                 # vh_conv scheduling hint: 0 = library default (the 512x128 tile staggers, the others do not)
         # attn_qkv / x_attn_kv write q, k, v^T from their own epilogue (needs the 16x16x32-MFMA glds kernel)
         self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0" and os.environ.get("VIVID_CONV_MFMA", "16") != "32"
         self.cfg = cfg
@@ -164,8 +164,6 @@ class Engine:
         self._ensure_ctx(device)
         self.zeros = torch.zeros(16384, dtype=torch.float32, device=device)     # 64 KiB zero page for vh_conv
         self.scratch = torch.empty(16 << 20, dtype=torch.float32, device=device) if self.glds else None   # split-K partial sums (64 MiB)
-        if self.glds:
-            self.conv_stagger = _autotune_conv(self.ctx, device, self.zeros, self.scratch)
         self.W.clear()
         self.embW.clear()
         self.programs.clear()
@@ -757,52 +755,6 @@ class Engine:
 
 
 L_PRO_SILU = 1
-_TUNED: Dict[int, int] = {}
-
-
-def _autotune_conv(ctx, device, zeros, scratch) -> int:
-    """Which DMA-issue order the 256-row glds convolution tiles run faster with on THIS device (vh_conv_args.stagger):
-    identical results, but the sign of the difference changes from one MI355X to the next (+6..9 % / -1.5..3 %),
-    so it is measured once per process and device: a 256->256 3x3 convolution on 4 x 128 x 128 pixels, both orders, interleaved.
-    VIVID_CONV_STAGGER (read by the library) still overrides; VIVID_CONV_AUTOTUNE=0 keeps the library default."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx in _TUNED:
-        return _TUNED[idx]
-    if os.environ.get("VIVID_CONV_AUTOTUNE", "1") == "0" or "VIVID_CONV_STAGGER" in os.environ:
-        _TUNED[idx] = 0
-        return 0
-    rows, h, w, cin, cout = 4, 128, 128, 256, 256
-    M, k_pad = rows * h * w, 9 * cin
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(M * cin, generator=g).to(device)                 # any finite bits do as an S8 tensor for timing
-    wt = torch.randn(k_pad * cout, generator=g).to(device)
-    out = torch.empty(M * cout, dtype=torch.float32, device=device)
-
-    def args(mode):
-        return L.ConvArgs(src0=x.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0,
-                          wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536,
-                          scratch=scratch.data_ptr() if scratch is not None else None, scratch_floats=scratch.numel() if scratch is not None else 0,
-                          cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=0, cvec=None, cvec_ld=0,
-                          res=None, res_up=0, ta=0.0, tb=0.0, clip=0.0, qkv=None, stagger=mode)
-
-    best = {1: float("inf"), 2: float("inf")}
-    with torch.cuda.device(device):
-        for mode in (1, 2):
-            ctx.call("vh_conv", args(mode))                            # warm-up (code objects, clocks)
-        for _ in range(3):
-            for mode in (1, 2):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(8):
-                    ctx.call("vh_conv", args(mode))
-                e1.record()
-                e1.synchronize()
-                best[mode] = min(best[mode], e0.elapsed_time(e1))
-    # stagger only when it wins clearly; 0 = library default (512-row tiles staggered, 256-row tiles not)
-    _TUNED[idx] = 1 if best[1] < 0.985 * best[2] else 0
-    return _TUNED[idx]
-
-
 L_EPI_SCALE_SILU = 1
 L_EPI_MPSUM = 2
 L_EPI_QKV = 3

@@ -151,13 +151,11 @@ def read_snapshot(f: Union[str, BinaryIO]) -> Dict[str, Any]:
     return _Unpickler(f).load()
 
 
-def load_network_pkl(f: Union[str, BinaryIO], key: Optional[str] = None, *, dual_source: bool = True,
-                     precision: Optional[str] = None):
-    """Build a `vivid_amd.NVPrecond` from a reference snapshot: `data['ema']` (or `data['net']`), as
+def network_from_snapshot(data, key: Optional[str] = None, *, dual_source: bool = True, precision: Optional[str] = None):
+    """`vivid_amd.NVPrecond` from decoded snapshot data (:func:`read_snapshot`): `data['ema']` (or `data['net']`), as
     `generate_images.py:169` picks it.  Weights are stored in fp16 by the reference (`training_loop.py:489`) and are
     widened to fp32 here, as the reference's `MPConv` does on every forward (`training/models.py:115`)."""
     from .net import NVPrecond
-    data = read_snapshot(f)
     if isinstance(data, SnapshotNet):
         rec = data
     else:
@@ -174,6 +172,12 @@ def load_network_pkl(f: Union[str, BinaryIO], key: Optional[str] = None, *, dual
     net = NVPrecond(**kw, dual_source=dual_source)
     net.load_state_dict({k: v.to(torch.float32) for k, v in rec.state_dict().items()}, strict=True)
     return net.eval()
+
+
+def load_network_pkl(f: Union[str, BinaryIO], key: Optional[str] = None, *, dual_source: bool = True,
+                     precision: Optional[str] = None):
+    """Read a reference snapshot file and build the network it holds (see :func:`network_from_snapshot`)."""
+    return network_from_snapshot(read_snapshot(f), key, dual_source=dual_source, precision=precision)
 
 
 def snapshot_encoder(data: Dict[str, Any]):
