@@ -112,11 +112,11 @@ enum { VH_PRO_NONE = 0, VH_PRO_SILU = 1 };
 enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2, VH_EPI_QKV = 3 };
 /* VH_EPI_QKV (1x1 conv, VH_CONV_GLDS256): the attn_qkv / x_attn_kv convolution writes the attention operands itself
  * instead of an fp32 tensor that vh_qkv_split_x3 would read back: per pixel and head, q / k / v are RMS-normalised
- * over their 64 channels (normalize(dim=2), training/models.py:192-194, :279-293) in the accumulators and stored as
+ * over their D channels (normalize(dim=2), training/models.py:192-194, :279-293) in the accumulators and stored as
  * vh_qkv_split_x3 stores them (same formats, same buffers, same arguments).  The OUTPUT CHANNELS of the weight must be
- * ordered [head][j][d] (o' = (head*nj + j)*64 + d) instead of the reference's (head*64 + d)*nj + j, so that a wave's
- * 64-column accumulator slab is one (head, j): permute the rows of w before vh_prep_weight.
- * Requires d == 64, s % 32 == 0, koff % 16 == 0, cout == heads*64*nj, out == NULL. */
+ * ordered [head][j][d] (o' = (head*nj + j)*D + d) instead of the reference's (head*D + d)*nj + j, so that a 64- (D = 64) or
+ * 32-column (D = 32) accumulator slab is one (head, j): permute the rows of w before vh_prep_weight.
+ * Requires D = cout / (heads*nj) == 64 or 32, s % 32 == 0, koff % 16 == 0, out == NULL. */
 typedef struct {
     float* q; void* k; void* v;            /* as vh_qkv_split_args (q unused for nj == 2) */
     int heads, nj, rows_per_b, koff, kl;   /* s = h*w of the convolution; rows = its rows */

@@ -103,7 +103,10 @@ def test_sr_cascade_matches_oracle_pipeline():
     bcfg, scfg = CASES["tiny_dual"]["cfg"], CASES["tiny_sr"]["cfg"]
     base, sr = _mk(bcfg, 3), _mk_sr(scfg, 9)
     seeds = [16, 17]
-    out = list(generate_images_nvs(base, seeds=seeds, max_batch_size=2, data=_data(4, 16, 3), sr_model=sr, num_steps=2, rng_device="cpu"))
+    # 4 steps per stage: the last Heun correction divides by t_next = sigma_min = 0.002, so a 2-step schedule (80 -> 0.002 in one
+    # step) amplifies any rounding difference in D by 0.5*80/0.002 = 2e4 - in the reference as much as here
+    steps = 4
+    out = list(generate_images_nvs(base, seeds=seeds, max_batch_size=2, data=_data(4, 16, 3), sr_model=sr, num_steps=steps, rng_device="cpu"))
     assert out[0].images.shape == (2, 3, 32, 32) and out[0].images.dtype == torch.uint8
     assert out[0].noise.shape == (4, 3, 32, 32) and out[0].src.shape == (2, 3, 32, 32)
     batch = next(_data(4, 16, 3))
@@ -114,11 +117,11 @@ def test_sr_cascade_matches_oracle_pipeline():
     obase = R.OracleNet(R.make_config(**d), vivid_amd.synth_state_dict(bcfg, seed=3))
     osr = R.OracleNet(R.make_config(**sd_), vivid_amd.synth_state_dict(scfg, seed=9))
     noise = rep(R.StackedRandomGenerator("cpu", seeds).randn([2, 3, 16, 16]))
-    lat = R.edm_sampler(obase, rep(R.encode_latents(pick("src_image"))), noise, labels=rep(pick("geometry")), gnet=obase, num_steps=2)
+    lat = R.edm_sampler(obase, rep(R.encode_latents(pick("src_image"))), noise, labels=rep(pick("geometry")), gnet=obase, num_steps=steps)
     low = torch.nn.functional.interpolate(lat, size=(32, 32), mode="bilinear", align_corners=False, antialias=True)
     sr_noise = rep(R.StackedRandomGenerator("cpu", seeds).randn([2, 3, 32, 32]))
     sr_lat = R.edm_sampler(osr, rep(R.encode_latents(pick("sr_src_image"))), sr_noise, labels=rep(pick("sr_geometry")), gnet=osr,
-                           conditioning_image=low, num_steps=2)
+                           conditioning_image=low, num_steps=steps)
     ref = R.decode_latents(sr_lat)
     diff = (out[0].images.cpu().int() - ref.int()).abs()
     assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.01

@@ -368,15 +368,16 @@ def test_qkv_split_and_attention(ctx, x3, b, heads, s, kl, d, nz):
     assert rel_l2(out.cpu(), ref.permute(0, 2, 1)) < (1e-4 if x3 else 2e-5)
 
 
+@pytest.mark.parametrize("D", [64, 32])
 @pytest.mark.parametrize("rows,nsrc,hw,heads,cin,koff_extra", [(2, 1, (8, 8), 2, 64, 0), (1, 1, (16, 16), 3, 96, 0), (4, 2, (8, 4), 1, 64, 0),
                                                               (2, 1, (32, 32), 4, 256, 0)])
-def test_conv_qkv_epilogue_matches_split_kernel(ctx, rows, nsrc, hw, heads, cin, koff_extra):
+def test_conv_qkv_epilogue_matches_split_kernel(ctx, rows, nsrc, hw, heads, cin, koff_extra, D):
     """VH_EPI_QKV: the 1x1 attn_qkv / x_attn_kv convolution writes q, k (S8) and v^T itself.  Checked against the
     unfused pair it replaces on the same inputs: vh_conv (fp32 out) -> vh_qkv_split_x3, buffer for buffer
     (normalize(dim=2)/unbind/concat of models.py:192-194, :279-297)."""
     from vivid_amd import _lib as L
     h, w = hw
-    S, D = h * w, 64
+    S = h * w                                                   # D = 64: base nets; D = 32: the super-resolution UNet (:578)
     g = torch.Generator().manual_seed(rows * 31 + cin + heads)
     for nj, rpb in ((3, 1), (2, nsrc)):
         if nj == 2 and rows % rpb:

@@ -33,7 +33,25 @@ struct AttnXK {
     int heads, s, kl, klp, c;
     float n_zero;
     int out_s8;
+    int nx, ny;                 // query tiles per (batch, head); number of (batch, head) pairs; the grid is 1-D with nx*ny workgroups
 };
+
+// Workgroup -> (query tile, batch*head).  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with
+// the plain order the query tiles of one (batch, head) are spread over all 8 and each XCD streams that head's K/V from beyond its
+// L2 for its share of the tiles (measured: 4.9x the algorithmic bytes cross the fabric).  Here every (batch, head) belongs to
+// one XCD (its workgroups are ids xcd, xcd+8, ...): its query tiles run side by side on that XCD's 32 CUs and walk the same K/V
+// tiles at about the same time.  Placement is a speed matter only; any mapping is correct.
+__device__ __forceinline__ void attn_coords(const AttnXK& a, int& bx, int& by) {
+    const unsigned bid = blockIdx.x;
+    if ((a.ny & 7) == 0) {
+        const unsigned xcd = bid & 7u, i = bid >> 3;
+        by = (int)(xcd + 8u * (i / (unsigned)a.nx));
+        bx = (int)(i % (unsigned)a.nx);
+    } else {
+        bx = (int)(bid % (unsigned)a.nx);
+        by = (int)(bid / (unsigned)a.nx);
+    }
+}
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float v) {
     return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)v);
@@ -59,9 +77,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
 
     const int t = threadIdx.x;
     const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
-    const int bh = blockIdx.y;
+    int bx, bh;
+    attn_coords(a, bx, bh);
     const int b = bh / a.heads, hd = bh - b * a.heads;
-    const int q0 = blockIdx.x * (NW * 32) + wv * 32;
+    const int q0 = bx * (NW * 32) + wv * 32;
     const int qrow = q0 + lr;
 
     // ---- Q fragments -------------------------------------------------------------------------
@@ -295,9 +314,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 
     const int t = threadIdx.x;
     const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
-    const int bh = blockIdx.y;
+    int bx, bh;
+    attn_coords(a, bx, bh);
     const int b = bh / a.heads, hd = bh - b * a.heads;
-    const int qrow = blockIdx.x * 256 + wv * 32 + lr;
+    const int qrow = bx * 256 + wv * 32 + lr;
 
     bf16x8 qh[D / 16], ql[D / 16];
     {
@@ -357,19 +377,31 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 #pragma unroll
         for (int i = 0; i < VPT; ++i) { rv[i] = *vp[i]; vp[i] += KT / 8; }
     };
-    auto storeK = [&](int slot, int k0, bool tail) {
+    // `tail` (the ragged last tile only) is tested ONCE per call: the full-tile path carries no mask arithmetic (with the test
+    // inside the element loops hipcc evaluated 14 compares + selects per tile whether or not a tail existed)
+    auto storeK = [&](int slot, int k0, bool tail) __attribute__((always_inline)) {
+        if (!tail) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) sK[slot][ksl[i]] = rk[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             uint4 v = rk[i];
-            if (tail && k0 + kkey[i] >= a.kl) v = zero4;
+            if (k0 + kkey[i] >= a.kl) v = zero4;
             sK[slot][ksl[i]] = v;
         }
     };
-    auto storeV = [&](int slot, int k0, bool tail) {
+    auto storeV = [&](int slot, int k0, bool tail) __attribute__((always_inline)) {
+        if (!tail) {
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) sV[slot][vsl[i]] = rv[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             uint4 v = rv[i];
-            if (tail && k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {
+            if (k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {
                 unsigned short* e = reinterpret_cast<unsigned short*>(&v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -398,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         for (int r = 0; r < 16; ++r)
             if (kbase + (r & 3) + 8 * (r >> 2) >= a.kl) sacc[r] = -INFINITY;
     };
-    auto qk = [&](f32x16& sacc, int slot, int ks) {
+    auto qk = [&](f32x16& sacc, int slot, int ks) __attribute__((always_inline)) {
         const int key = ks * 32 + lr;
 #pragma unroll
         for (int sl = 0; sl < D / 16; ++sl) {
@@ -416,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     // one pipeline step: finish sub-tile (vslot, vks) whose logits are in scur; start the next one if any
     // (the sub-tile after the last one is computed too, from whatever the idle K slot holds, and never used: a
     // `has_next` branch around qk() would cut region B in two and its MFMAs would issue without the VALU work)
-    auto step = [&](int vslot, int vks, int nslot, int nks, int nk0, bool ntail) {
+    auto step = [&](int vslot, int vks, int nslot, int nks, int nk0, bool ntail) __attribute__((always_inline)) {
         // region A: row max of the current logits (scur = s - m), rare raise of the running max
         float mx = 0.f;
         if constexpr (!NOMAX) {
@@ -486,18 +518,33 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         for (int r = 0; r < 16; ++r) { scur[r] -= mx; negm[r] = -mx; }
     }
 
-    int ks0 = 0, ks1 = 1, ks2 = 2;                          // K slots of tiles t, t+1, t+2
-    for (int tile = 0; tile < ntiles; ++tile) {
+    // One tile with its LDS slots as compile-time constants: K slots of tiles t, t+1, t+2 are (t, t+1, t+2) mod 3, the V slot t mod 2,
+    // so the pattern repeats every 6 tiles and the loop dispatches on t mod 6.  With run-time slot numbers every ds_read address
+    // was rebuilt per step (12 v_lshl_add + 7 v_or of ~100 VALU per 24 MFMAs, in a loop whose limiter is VALU issue).
+    auto one_tile = [&](auto k0c, auto k1c, auto k2c, auto vc, int tile) __attribute__((always_inline)) {
+        constexpr int KS0 = decltype(k0c)::value, KS1 = decltype(k1c)::value, KS2 = decltype(k2c)::value, VS = decltype(vc)::value;
         const int k0 = tile * KT;
         const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
         if (more2) loadK();
         if (more1) loadV();
-        step(tile & 1, 0, ks0, 1, k0, is_tail(tile));
-        step(tile & 1, 1, ks1, 0, k0 + KT, is_tail(tile + 1));
-        if (more2) storeK(ks2, k0 + 2 * KT, is_tail(tile + 2));
-        if (more1) storeV((tile + 1) & 1, k0 + KT, is_tail(tile + 1));
+        step(VS, 0, KS0, 1, k0, is_tail(tile));
+        step(VS, 1, KS1, 0, k0 + KT, is_tail(tile + 1));
+        if (more2) storeK(KS2, k0 + 2 * KT, is_tail(tile + 2));
+        if (more1) storeV(VS ^ 1, k0 + KT, is_tail(tile + 1));
         __syncthreads();
-        const int tmp = ks0; ks0 = ks1; ks1 = ks2; ks2 = tmp;
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    int phase = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        switch (phase) {
+            case 0: one_tile(I0{}, I1{}, I2{}, I0{}, tile); break;
+            case 1: one_tile(I1{}, I2{}, I0{}, I1{}, tile); break;
+            case 2: one_tile(I2{}, I0{}, I1{}, I0{}, tile); break;
+            case 3: one_tile(I0{}, I1{}, I2{}, I1{}, tile); break;
+            case 4: one_tile(I1{}, I2{}, I0{}, I0{}, tile); break;
+            default: one_tile(I2{}, I0{}, I1{}, I1{}, tile); break;
+        }
+        phase = phase == 5 ? 0 : phase + 1;
     }
 
     if (qrow < a.s && a.out_s8) {
@@ -671,7 +718,7 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     VH_REQUIRE(a.n_zero_keys >= 0.f, "vh_attention_x3: negative n_zero_keys");
     const int klp = (a.kl + KT - 1) / KT * KT;
     AttnXK k{a.q, static_cast<const uint4*>(static_cast<const void*>(a.k)), static_cast<const uint4*>(static_cast<const void*>(a.v)),
-             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys, a.out_s8};
+             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys, a.out_s8, 0, 0};
     VH_REQUIRE(!a.out_s8 || (a.heads * a.d) % 32 == 0, "vh_attention_x3: S8 output needs heads*d %% 32 == 0");
     const int d = a.d;
     // One 8-wave workgroup per CU for long sequences (two independent 4-wave workgroups per CU measured 2.4x
@@ -682,7 +729,10 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     VH_REQUIRE(a.logit_bound >= 0.f, "vh_attention_x3: negative logit_bound");
     static const bool nomax_on = !(getenv("VIVID_ATTN_NOMAX") && atoi(getenv("VIVID_ATTN_NOMAX")) == 0);
     const bool nomax = nomax_on && a.logit_bound > 0.f && a.logit_bound <= 64.f;
-    const dim3 grid((a.s + nw * 32 - 1) / (nw * 32), a.b * a.heads);
+    k.nx = (a.s + nw * 32 - 1) / (nw * 32);
+    k.ny = a.b * a.heads;
+    VH_REQUIRE((long long)k.nx * k.ny < (1LL << 31), "vh_attention_x3: grid too large");
+    const dim3 grid((unsigned)(k.nx * k.ny));
     const double bhd = (double)a.b * a.heads;
     const double flops = 4.0 * bhd * a.s * a.kl * a.d;
     const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);

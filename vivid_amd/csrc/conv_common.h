@@ -20,7 +20,7 @@ struct ConvK {
     float ta, tb, clip;
     int M, HW, NT;
     // VH_EPI_QKV: attention operand buffers and the key-sequence placement of vh_qkv_split_x3
-    float* q; unsigned short* qk; unsigned short* qv; int q_heads, q_nj, q_rows_per_b, q_koff, q_klp; float q_scale;
+    float* q; unsigned short* qk; unsigned short* qv; int q_heads, q_nj, q_rows_per_b, q_koff, q_klp, q_d; float q_scale;
     int stagger;                    // conv_x3_glds: waves 4-7 issue their DMA in the middle of their MFMAs instead of before them
     int korder;                     // conv_x3_glds, 9 taps: 0 = tap-major K order, 1 = channel-chunk-major (see the kernel)
     int ksplit; float* scratch;     // split-K: this launch covers K-tiles [ks*KT/ksplit, (ks+1)*KT/ksplit) and

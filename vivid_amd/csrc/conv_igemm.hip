@@ -259,7 +259,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
         VH_REQUIRE(a.qkv && a.taps == 1 && a.kernel == VH_CONV_GLDS256 && !a.out && !a.out_s8, "vh_conv: QKV epilogue needs qkv args, a 1x1 GLDS convolution and no other output");
         const vh_qkv_epilogue& e = *a.qkv;
         VH_REQUIRE((e.nj == 2 || (e.nj == 3 && e.q)) && e.k && e.v, "vh_conv: QKV epilogue: nj must be 2 or 3 (3 needs q), k and v given");
-        VH_REQUIRE(e.heads > 0 && a.cout == e.heads * 64 * e.nj, "vh_conv: QKV epilogue: cout %d != heads*64*nj", a.cout);
+        VH_REQUIRE(e.heads > 0 && (a.cout == e.heads * 64 * e.nj || a.cout == e.heads * 32 * e.nj), "vh_conv: QKV epilogue: cout %d != heads*D*nj with D = 64 or 32", a.cout);
         VH_REQUIRE((a.h * a.w) % 32 == 0 && e.koff % 16 == 0 && e.koff >= 0, "vh_conv: QKV epilogue needs h*w %% 32 == 0 and koff %% 16 == 0");
         VH_REQUIRE(e.rows_per_b > 0 && a.rows % e.rows_per_b == 0 && e.koff + e.rows_per_b * a.h * a.w <= e.kl, "vh_conv: QKV epilogue: keys do not fit");
         VH_REQUIRE(vh_aligned16(e.q) && vh_aligned16(e.k) && vh_aligned16(e.v), "vh_conv: QKV epilogue: pointers must be 16-byte aligned");
@@ -280,11 +280,11 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
     k.ksplit = 1; k.scratch = nullptr; k.korder = 0; k.stagger = 0;
-    k.q = nullptr; k.qk = k.qv = nullptr; k.q_heads = k.q_nj = k.q_rows_per_b = k.q_koff = k.q_klp = 0; k.q_scale = 1.f;
+    k.q = nullptr; k.qk = k.qv = nullptr; k.q_heads = k.q_nj = k.q_rows_per_b = k.q_koff = k.q_klp = 0; k.q_d = 64; k.q_scale = 1.f;
     if (a.epi == VH_EPI_QKV) {
         const vh_qkv_epilogue& e = *a.qkv;
         k.q = e.q; k.qk = static_cast<unsigned short*>(e.k); k.qv = static_cast<unsigned short*>(e.v);
-        k.q_heads = e.heads; k.q_nj = e.nj; k.q_rows_per_b = e.rows_per_b; k.q_koff = e.koff; k.q_klp = (e.kl + 63) / 64 * 64; k.q_scale = e.qscale;
+        k.q_heads = e.heads; k.q_nj = e.nj; k.q_rows_per_b = e.rows_per_b; k.q_koff = e.koff; k.q_klp = (e.kl + 63) / 64 * 64; k.q_d = a.cout / (e.heads * e.nj); k.q_scale = e.qscale;
     }
     VH_REQUIRE(!a.scratch || vh_aligned16(a.scratch), "vh_conv: scratch must be 16-byte aligned");
     const int taps = a.taps, prec = a.prec;

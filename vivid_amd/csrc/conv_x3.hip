@@ -316,24 +316,40 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     float* patch = reinterpret_cast<float*>(&sA[0][0]) + w * (32 * 36);
     if constexpr (TAPS == 1 && M16 && NI == 2) {
         if (a.epi == VH_EPI_QKV) {
-            // Fused q/k/v split (see VH_EPI_QKV in vivid_hip.h).  This wave's 64 accumulator columns are one (head, j).
-            const int slab = (n0 + wn * 64) >> 6;
-            if (slab * 64 >= a.cout) return;
-            const int head = slab / a.q_nj, j = slab - head * a.q_nj;
-            const bool is_q = a.q_nj == 3 && j == 0, is_k = a.q_nj == 3 ? j == 1 : j == 0;
-            // 1. RMS-normalise every pixel row over the 64 channels, in the accumulators (C/D map: column = lane&15 of each of
-            //    the 4 column tiles, row = 4*(lane>>4) + r): square-sum over the 4 tiles, then over the 16 lanes of the row.
+            // Fused q/k/v split (see VH_EPI_QKV in vivid_hip.h).  With 64-channel heads this wave's 64 accumulator columns are one
+            // (head, j); with 32-channel heads (the super-resolution UNet) each 32-column half is one.
+            const int colw = n0 + wn * 64;
+            if (colw >= a.cout) return;
+            const int D = a.q_d;
+            const float rsd = D == 64 ? 0.125f : 0.17677669529663687f;            // 1/sqrt(D)
+            int head_[NI], j_[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int sl = D == 64 ? (colw >> 6) : ((colw >> 5) + ni);
+                head_[ni] = sl / a.q_nj;
+                j_[ni] = sl - head_[ni] * a.q_nj;
+            }
+            // 1. RMS-normalise every pixel row over the head's channels, in the accumulators (C/D map: column = lane&15 of each of
+            //    the 4 column tiles, row = 4*(lane>>4) + r): square-sum over the head's tiles, then over the 16 lanes of the row.
 #pragma unroll
             for (int mt = 0; mt < MI * 2; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float ss = 0.f;
+                    float ss[2];
 #pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl) ss += acc16[mt][ntl][r] * acc16[mt][ntl][r];
-                    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-                    const float sc = (is_q ? a.q_scale : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);     // 0.125 = 1/sqrt(64)
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float t2 = acc16[mt][2 * ni][r] * acc16[mt][2 * ni][r] + acc16[mt][2 * ni + 1][r] * acc16[mt][2 * ni + 1][r];
+                        t2 += __shfl_xor(t2, 1); t2 += __shfl_xor(t2, 2); t2 += __shfl_xor(t2, 4); t2 += __shfl_xor(t2, 8);
+                        ss[ni] = t2;
+                    }
+                    if (D == 64) ss[0] = ss[1] = ss[0] + ss[1];
 #pragma unroll
-                    for (int ntl = 0; ntl < 4; ++ntl) acc16[mt][ntl][r] *= sc;
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const bool isq = a.q_nj == 3 && j_[ni] == 0;
+                        const float sc = (isq ? a.q_scale : 1.f) / (1e-4f + sqrtf(ss[ni]) * rsd);
+                        acc16[mt][2 * ni][r] *= sc;
+                        acc16[mt][2 * ni + 1][r] *= sc;
+                    }
                 }
             }
             // 2. per 32x32 block: through the wave's LDS patch, then rows (q, k) or columns (v^T) of it go out as 16-byte units
@@ -344,6 +360,10 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                 for (int ni = 0; ni < NI; ++ni) {
                     const int row0 = m0 + (wm * MI + mi) * 32;
                     if (row0 >= a.M) continue;                              // (M % 32 == 0: blocks are all-in or all-out)
+                    if (colw + ni * 32 >= a.cout) continue;                  // (32-channel heads: cout need not fill the wave's 64 columns)
+                    const int head = head_[ni], j = j_[ni];
+                    const bool is_q = a.q_nj == 3 && j == 0, is_k = a.q_nj == 3 ? j == 1 : j == 0;
+                    const int dbase = D == 64 ? ni * 32 : 0;                // first head channel of this block
                     constexpr int LD = 36;
                     {
                         const int c = l & 15, rb = (l >> 4) * 4;
@@ -365,9 +385,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                         for (int i = 0; i < 4; ++i) {
                             const int rl = rsub + 8 * i;
                             const float4 v = *reinterpret_cast<const float4*>(&patch[rl * LD + 4 * cg]);
-                            const int d0 = ni * 32 + 4 * cg;
+                            const int d0 = dbase + 4 * cg;
                             if (is_q) {
-                                *reinterpret_cast<float4*>(a.q + (bhq * S + s0 + rl) * 64 + d0) = v;
+                                *reinterpret_cast<float4*>(a.q + (bhq * S + s0 + rl) * D + d0) = v;
                             } else {
                                 const float y[4] = {v.x, v.y, v.z, v.w};
                                 unsigned h[4], lo[4];
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                                     h[e2] = bf16_rn_bits(y[e2]);
                                     lo[e2] = bf16_rn_bits(y[e2] - __uint_as_float(h[e2] << 16));
                                 }
-                                unsigned short* kp = a.qk + ((bhq * a.q_klp + key0 + rl) * 64 + (d0 & ~7)) * 2 + (d0 & 7);
+                                unsigned short* kp = a.qk + ((bhq * a.q_klp + key0 + rl) * D + (d0 & ~7)) * 2 + (d0 & 7);
                                 *reinterpret_cast<uint2*>(kp) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
                                 *reinterpret_cast<uint2*>(kp + 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
                             }
@@ -384,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                     } else {
                         // V^T [bh][d][hl][klp], positions permuted inside 16-key groups (bits 2,3 swapped): lane = channel c and
                         // half the block's 4 units of 8 positions
-                        const int c = l & 31, d = ni * 32 + c;
+                        const int c = l & 31, d = dbase + c;
 #pragma unroll
                         for (int uu = 0; uu < 2; ++uu) {
                             const int unit = (l >> 5) * 2 + uu;                // 8 positions 8*unit .. of the 32-key block
@@ -397,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                                 h[e2] = bf16_rn_bits(y);
                                 lo[e2] = bf16_rn_bits(y - __uint_as_float(h[e2] << 16));
                             }
-                            unsigned short* vp = a.qv + ((bhq * 64 + d) * 2) * (size_t)a.q_klp + key0 + unit * 8;
+                            unsigned short* vp = a.qv + ((bhq * D + d) * 2) * (size_t)a.q_klp + key0 + unit * 8;
                             *reinterpret_cast<uint4*>(vp) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
                             *reinterpret_cast<uint4*>(vp + a.q_klp) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
                         }

@@ -192,10 +192,10 @@ class Engine:
                     self._prep_conv(p + "conv_skip.weight", 1)
                 if b.heads:
                     fused = self._qkv_fused(b)
-                    self._prep_conv(p + "attn_qkv.weight", 1, qkv_perm=3 if fused else 0)
+                    self._prep_conv(p + "attn_qkv.weight", 1, qkv_perm=(3, b.cout // b.heads) if fused else None)
                     self._prep_conv(p + "attn_proj.weight", 1)
                     if b.xattn:
-                        self._prep_conv(p + "x_attn_kv.weight", 1, qkv_perm=2 if fused else 0)
+                        self._prep_conv(p + "x_attn_kv.weight", 1, qkv_perm=(2, b.cout // b.heads) if fused else None)
                 w = params[p + "emb_linear.weight"]
                 a = L.PrepWeightArgs(w=w.data_ptr(), cout=b.cout, cin=spec.cemb, taps=1, cin_pad=_round_up(spec.cemb, 4),
                                      k_pad=kpad, gain_ptr=params[p + "emb_gain"].data_ptr(), gain_value=1.0,
@@ -210,17 +210,18 @@ class Engine:
 
     def _qkv_fused(self, b: BlockSpec) -> bool:
         """attn_qkv / x_attn_kv write the attention operands from their own epilogue (VH_EPI_QKV) instead of an fp32
-        tensor that vh_qkv_split_x3 reads back: bf16x3 glds path, 64-channel heads, 32 | pixels per image."""
+        tensor that vh_qkv_split_x3 reads back: bf16x3 glds path, 64- or 32-channel heads, 32 | pixels per image."""
         if not (self.x3 and self.glds and self.fuse_qkv and b.heads):
             return False
-        return b.cout % 32 == 0 and b.cin % 32 == 0 and b.cout // b.heads == 64 and (b.res * b.res) % 32 == 0
+        return b.cout % 32 == 0 and b.cin % 32 == 0 and b.cout // b.heads in (32, 64) and (b.res * b.res) % 32 == 0
 
-    def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None, qkv_perm: int = 0):
+    def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None, qkv_perm: Optional[Tuple[int, int]] = None):
         w = self._params[key]
         if qkv_perm and w.numel():
-            # output channel (head*64 + d)*nj + j  ->  (head*nj + j)*64 + d: one (head, j) per 64-column accumulator slab
-            nj, heads = qkv_perm, w.shape[0] // (64 * qkv_perm)
-            w = w.view(heads, 64, nj, *w.shape[1:]).transpose(1, 2).contiguous().view(w.shape)
+            # output channel (head*D + d)*nj + j  ->  (head*nj + j)*D + d: one (head, j) per D-column accumulator slab
+            nj, D = qkv_perm
+            heads = w.shape[0] // (D * nj)
+            w = w.view(heads, D, nj, *w.shape[1:]).transpose(1, 2).contiguous().view(w.shape)
         cout, cin = w.shape[0], w.shape[1]
         # 2-D (linear) weights feed embed_k/linear_k: never split.  bf16x3 convs: split 2 = [cout][K] for the glds kernel
         split = (2 if self.glds else 1) if (self.x3 and w.ndim == 4) else 0
