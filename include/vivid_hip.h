@@ -46,6 +46,12 @@ int vh_ctx_create(void* stream, vh_ctx** out);
 int vh_ctx_destroy(vh_ctx* ctx);
 int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
 
+/* Process-wide diagnostic knobs, read when an op is issued or recorded; none changes results.  "attn_xcd": 1 (default) places
+ * every (batch, head) of the bf16x3 attention on one XCD, 0 keeps the plain workgroup order (A/B timing in one process);
+ * "dbg_lo" / "dbg_hi": the two halves of a device pointer that receives the clock stamps of the diagnostic builds
+ * (-DVH_CLOCK, tools/clock_probe.py) - the product build never writes to it.  Returns VH_EINVAL for an unknown name. */
+int vh_set_knob(const char* name, int value);
+
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline line).
  * While enabled, every launch (direct or replayed) is bracketed by two events and carries its
  * algorithmic FLOPs / HBM bytes; vh_profile_read synchronises the stream, sums them per

@@ -159,7 +159,7 @@ OPS = {
     "vh_nonzero_flag": NonzeroArgs, "vh_resample": ResampleArgs, "vh_moments": MomentsArgs, "vh_psnr_sum": PsnrArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
-CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream",
+CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
            "vh_plan_begin", "vh_plan_end", "vh_plan_abort", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
@@ -187,6 +187,7 @@ def lib():
     L.vh_profile_enable.argtypes = [C.c_void_p, C.c_int]
     L.vh_profile_read.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.vh_set_knob.argtypes = [C.c_char_p, C.c_int]
     L.vh_plan_begin.argtypes = [C.c_void_p]
     L.vh_plan_abort.argtypes = [C.c_void_p]
     L.vh_plan_end.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -202,6 +203,11 @@ def lib():
         getattr(L, name)
     _lib = L
     return L
+
+
+def set_knob(name: str, value: int):
+    """Process-wide scheduling knob of the library (vh_set_knob): for A/B measurements, never needed for results."""
+    check(lib().vh_set_knob(name.encode(), int(value)), "vh_set_knob")
 
 
 def check(rc: int, what: str = ""):

@@ -6,6 +6,18 @@ std::string& vh_err() {
     return e;
 }
 
+static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0};
+static const char* const g_knob_names[VH_NUM_KNOBS] = {"attn_xcd", "dbg_lo", "dbg_hi"};
+
+int vh_knob(int id) { return (id >= 0 && id < VH_NUM_KNOBS) ? g_knobs[id] : 0; }
+
+extern "C" int vh_set_knob(const char* name, int value) {
+    if (!name) return vh_fail(VH_EINVAL, "vh_set_knob: null name");
+    for (int i = 0; i < VH_NUM_KNOBS; ++i)
+        if (std::string(name) == g_knob_names[i]) { g_knobs[i] = value; return VH_OK; }
+    return vh_fail(VH_EINVAL, "vh_set_knob: unknown knob '%s'", name);
+}
+
 extern "C" int vh_abi_version(void) { return VH_ABI_VERSION; }
 
 extern "C" const char* vh_last_error(void) { return vh_err().c_str(); }

@@ -27,6 +27,9 @@ namespace {
 
 constexpr int KT = 64;
 constexpr float RESCALE_THR = 8.0f;
+#ifndef VH_ATTN_STATIC_SLOTS
+#define VH_ATTN_STATIC_SLOTS 0     // 1: compile-time LDS slot numbers in the pipelined kernel (6-phase loop): 20 % fewer VALU instructions, measured 10 % SLOWER
+#endif
 
 struct AttnXK {
     const float* q; const uint4* k; const uint4* vt; float* out;
@@ -34,6 +37,8 @@ struct AttnXK {
     float n_zero;
     int out_s8;
     int nx, ny;                 // query tiles per (batch, head); number of (batch, head) pairs; the grid is 1-D with nx*ny workgroups
+    int xcd;                    // 1: XCD-local (batch, head) placement
+    unsigned long long* dbg;    // VH_CLOCK builds: [workgroup][2] = shader cycles, 100 MHz ticks of the key loop
 };
 
 // Workgroup -> (query tile, batch*head).  Workgroup ids are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so with
@@ -43,7 +48,7 @@ struct AttnXK {
 // tiles at about the same time.  Placement is a speed matter only; any mapping is correct.
 __device__ __forceinline__ void attn_coords(const AttnXK& a, int& bx, int& by) {
     const unsigned bid = blockIdx.x;
-    if ((a.ny & 7) == 0) {
+    if (a.xcd && (a.ny & 7) == 0) {
         const unsigned xcd = bid & 7u, i = bid >> 3;
         by = (int)(xcd + 8u * (i / (unsigned)a.nx));
         bx = (int)(i % (unsigned)a.nx);
@@ -145,16 +150,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
         for (int i = 0; i < VPT; ++i) { rv[i] = *vp[i]; vp[i] += KT / 8; }
     };
     auto store_tile = [&](int buf, int k0, bool tail) {
+        if (!tail) {                                             // full tiles carry no mask arithmetic
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) sK[buf][ksl[i]] = rk[i];
+#pragma unroll
+            for (int i = 0; i < VPT; ++i) sV[buf][vsl[i]] = rv[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KPT; ++i) {
             uint4 v = rk[i];
-            if (tail && k0 + kkey[i] >= a.kl) v = zero4;
+            if (k0 + kkey[i] >= a.kl) v = zero4;
             sK[buf][ksl[i]] = v;
         }
 #pragma unroll
         for (int i = 0; i < VPT; ++i) {
             uint4 v = rv[i];
-            if (tail && k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {   // the unit's 16-key group reaches past the end
+            if (k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {           // the unit's 16-key group reaches past the end
                 unsigned short* e = reinterpret_cast<unsigned short*>(&v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -533,6 +545,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         if (more1) storeV(VS ^ 1, k0 + KT, is_tail(tile + 1));
         __syncthreads();
     };
+#ifdef VH_CLOCK
+    unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+#if VH_ATTN_STATIC_SLOTS
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     int phase = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
@@ -546,6 +563,37 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         }
         phase = phase == 5 ? 0 : phase + 1;
     }
+#else   // run-time slot numbers (A/B reference)
+    (void)one_tile;
+    int ks0 = 0, ks1 = 1, ks2 = 2;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int k0 = tile * KT;
+        const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
+#if defined(VH_ATTN_ABLATE) && (VH_ATTN_ABLATE & 1)   // timing ablation build (WRONG results): no K/V staging
+        (void)more1; (void)more2;
+        step(tile & 1, 0, ks0, 1, k0, false);
+        step(tile & 1, 1, ks1, 0, k0 + KT, false);
+#else
+        if (more2) loadK();
+        if (more1) loadV();
+        step(tile & 1, 0, ks0, 1, k0, is_tail(tile));
+        step(tile & 1, 1, ks1, 0, k0 + KT, is_tail(tile + 1));
+        if (more2) storeK(ks2, k0 + 2 * KT, is_tail(tile + 2));
+        if (more1) storeV((tile + 1) & 1, k0 + KT, is_tail(tile + 1));
+#endif
+#if !(defined(VH_ATTN_ABLATE) && (VH_ATTN_ABLATE & 2))   // timing ablation build (WRONG results): no tile barrier
+        __syncthreads();
+#endif
+        const int tmp = ks0; ks0 = ks1; ks1 = ks2; ks2 = tmp;
+    }
+#endif
+#ifdef VH_CLOCK
+    {
+        const unsigned long long ck_m1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (a.dbg && t == 0) { a.dbg[(size_t)blockIdx.x * 2] = ck_m1 - ck_m0; a.dbg[(size_t)blockIdx.x * 2 + 1] = ck_r1 - ck_r0; }
+    }
+#endif
 
     if (qrow < a.s && a.out_s8) {
         const float inv = 1.0f / lsum;
@@ -718,12 +766,13 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     VH_REQUIRE(a.n_zero_keys >= 0.f, "vh_attention_x3: negative n_zero_keys");
     const int klp = (a.kl + KT - 1) / KT * KT;
     AttnXK k{a.q, static_cast<const uint4*>(static_cast<const void*>(a.k)), static_cast<const uint4*>(static_cast<const void*>(a.v)),
-             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys, a.out_s8, 0, 0};
+             a.out, a.heads, a.s, a.kl, klp, a.heads * a.d, a.n_zero_keys, a.out_s8, 0, 0, vh_knob(VH_KNOB_ATTN_XCD), vh_debug_ptr()};
     VH_REQUIRE(!a.out_s8 || (a.heads * a.d) % 32 == 0, "vh_attention_x3: S8 output needs heads*d %% 32 == 0");
     const int d = a.d;
     // One 8-wave workgroup per CU for long sequences (two independent 4-wave workgroups per CU measured 2.4x
     // slower: every workgroup stages its own copy of the K/V stream).
-    const int nw = a.s > 128 ? 8 : 4;
+    // (64-channel heads always take the 8-wave form: its 4-wave instantiation needs more than 256 VGPRs and spills)
+    const int nw = (a.s > 128 || a.d == 64) ? 8 : 4;
     static const bool use_pipe = !(getenv("VIVID_ATTN_PIPE") && atoi(getenv("VIVID_ATTN_PIPE")) == 0);
     const bool pipe = use_pipe && nw == 8 && a.kl > KT;
     VH_REQUIRE(a.logit_bound >= 0.f, "vh_attention_x3: negative logit_bound");
@@ -742,7 +791,6 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
         else if (pipe && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32, true>), grid, dim3(512), 0, s, k);
         else if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32>), grid, dim3(512), 0, s, k);
         else if (d == 64 && nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 8>), grid, dim3(512), 0, s, k);
-        else if (d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3<64, 4>), grid, dim3(256), 0, s, k);
         else if (nw == 8) hipLaunchKernelGGL((attn_fwd_bf16x3<32, 8>), grid, dim3(512), 0, s, k);
         else hipLaunchKernelGGL((attn_fwd_bf16x3<32, 4>), grid, dim3(256), 0, s, k);
         return vh_check_launch("attn_fwd_bf16x3");

@@ -53,14 +53,21 @@ __device__ __forceinline__ void wait_dma() {
 // 16-deep v_mfma_f32_32x32x16_bf16 slabs: same cycles per FLOP, but the chip holds a higher clock on the 16x16
 // shape (MI355X_MICROARCH.md, DVFS give-back item 7).  The LDS unit order is then hl*4 + chunk (conflict-free
 // for the 16-row operand reads) instead of chunk*2 + hl; only the source-side mapping of the DMA changes.
-template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16>
+// CHUNK = true: channel-chunk-major K order (9 taps only).  A template parameter rather than a run-time flag so that each
+// instantiation keeps only ITS per-slot state in registers (pixel coordinates for tap-major, centre pointer + tap mask for
+// chunk-major): with both live the 512x128 tile needed 256 VGPRs + 40 bytes of scratch per lane.
+template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16, bool CHUNK>
 __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
+    static_assert(!CHUNK || TAPS == 9, "chunk-major order exists for 3x3 convolutions only");
     static_assert(WAVES_M * WAVES_N == 8, "8 waves");
     constexpr int BM = WAVES_M * MI * 32, BN = WAVES_N * NI * 32;
     constexpr int RA = BM / 64, RB = BN / 64;             // glds rounds: 512 slots (64 rows x 8 units) per round
     __shared__ float4 sA[2][BM * 8];
     __shared__ float4 sB[2][BN * 8];
 
+#ifdef VH_CLOCK
+    const unsigned long long ck_e0 = __builtin_amdgcn_s_memtime();
+#endif
     const int t = threadIdx.x;
     const int w = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
     const unsigned tile0 = xcd_tile_id();
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     // then centre + (dy*W + dx)*C (one scalar offset) or the zero page.  Not for `up` (the source offset is not uniform).
     const float4* pc[RA];
     unsigned pmask[RA];
-    if (TAPS == 9 && a.korder) {
+    if constexpr (CHUNK) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             unsigned m = 0;
@@ -245,9 +252,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     // at the full-resolution levels that is more than the 4 MB L2 and each tap re-fetches its input from beyond it (~5x the
     // algorithmic bytes, profiles/).  Chunk-major (the 9 taps of channels 0-31, then of 32-63, ...) re-uses a line within
     // 9 consecutive K-tiles.
-    const bool chunk_major = TAPS == 9 && a.korder;
+    constexpr bool chunk_major = CHUNK;
     int tap, cc;
-    if (chunk_major) { cc = (kt0 / 9) * BK; tap = kt0 - (kt0 / 9) * 9; setup_tap_fast(tap); }
+    if constexpr (chunk_major) { cc = (kt0 / 9) * BK; tap = kt0 - (kt0 / 9) * 9; setup_tap_fast(tap); }
     else { tap = (kt0 * BK) / a.cin_pad; cc = kt0 * BK - tap * a.cin_pad; setup_tap(tap); }
     issue(0, tap, cc);
     wait_dma();
@@ -273,12 +280,16 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
 #else
 #define VH_STAMP_AT(v)
 #endif
+#ifdef VH_CLOCK   // diagnostic build: shader clock (s_memtime) against the 100 MHz reference (s_memrealtime) around the K loop
+    unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (int kt = 0; kt < KT; ++kt) {
         const int st = kt & 1;
         VH_STAMP_AT(s0);
         auto fetch_next = [&]() {
             if (kt + 1 < KT) {
-                if (chunk_major) {
+                if constexpr (chunk_major) {
                     if (++tap == 9) { tap = 0; cc += BK; }
                     setup_tap_fast(tap);
                 } else {
@@ -304,6 +315,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         tacc[0] += s1 - s0; tacc[1] += s2 - s1; tacc[2] += s3 - s2; tacc[3] += s4 - s3;
 #endif
     }
+#ifdef VH_CLOCK
+    {
+        const unsigned long long ck_m1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (a.dbg && t == 0) {
+            a.dbg[(size_t)blockIdx.x * 4] = ck_m1 - ck_m0; a.dbg[(size_t)blockIdx.x * 4 + 1] = ck_r1 - ck_r0;
+            a.dbg[(size_t)blockIdx.x * 4 + 2] = ck_m0 - ck_e0;             // prologue: entry -> first K-tile
+        }
+    }
+    const unsigned long long ck_l1 = __builtin_amdgcn_s_memtime();
+#define VH_CLOCK_EXIT() do { const unsigned long long ck_x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+        if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 4 + 3] = ck_x - ck_l1; } while (0)     /* epilogue: instructions issued (stores not drained) */
+#else
+#define VH_CLOCK_EXIT()
+#endif
 #ifdef VH_STAMP   // stamps go to the split-K scratch (unused when ksplit == 1), never into an output
     if (a.scratch && a.ksplit == 1 && l == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.scratch) + ((size_t)blockIdx.x * 8 + w) * 6;
@@ -331,31 +357,27 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
             }
             // 1. RMS-normalise every pixel row over the head's channels, in the accumulators (C/D map: column = lane&15 of each of
             //    the 4 column tiles, row = 4*(lane>>4) + r): square-sum over the head's tiles, then over the 16 lanes of the row.
-#pragma unroll
-            for (int mt = 0; mt < MI * 2; ++mt) {
+            //    Done per 32-row group right before its blocks go out (short live ranges: no spills in this cold code).
+            auto normalise_rows = [&](f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3) __attribute__((always_inline)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float ss[2];
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        float t2 = acc16[mt][2 * ni][r] * acc16[mt][2 * ni][r] + acc16[mt][2 * ni + 1][r] * acc16[mt][2 * ni + 1][r];
-                        t2 += __shfl_xor(t2, 1); t2 += __shfl_xor(t2, 2); t2 += __shfl_xor(t2, 4); t2 += __shfl_xor(t2, 8);
-                        ss[ni] = t2;
-                    }
-                    if (D == 64) ss[0] = ss[1] = ss[0] + ss[1];
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const bool isq = a.q_nj == 3 && j_[ni] == 0;
-                        const float sc = (isq ? a.q_scale : 1.f) / (1e-4f + sqrtf(ss[ni]) * rsd);
-                        acc16[mt][2 * ni][r] *= sc;
-                        acc16[mt][2 * ni + 1][r] *= sc;
-                    }
+                    float s0 = t0[r] * t0[r] + t1[r] * t1[r], s1 = t2[r] * t2[r] + t3[r] * t3[r];
+                    s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
+                    s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
+                    s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4);
+                    s0 += __shfl_xor(s0, 8); s1 += __shfl_xor(s1, 8);
+                    if (D == 64) s0 = s1 = s0 + s1;
+                    const float c0 = ((a.q_nj == 3 && j_[0] == 0) ? a.q_scale : 1.f) / (1e-4f + sqrtf(s0) * rsd);
+                    const float c1 = ((a.q_nj == 3 && j_[1] == 0) ? a.q_scale : 1.f) / (1e-4f + sqrtf(s1) * rsd);
+                    t0[r] *= c0; t1[r] *= c0; t2[r] *= c1; t3[r] *= c1;
                 }
-            }
+            };
             // 2. per 32x32 block: through the wave's LDS patch, then rows (q, k) or columns (v^T) of it go out as 16-byte units
             const int S = a.HW;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                normalise_rows(acc16[2 * mi][0], acc16[2 * mi][1], acc16[2 * mi][2], acc16[2 * mi][3]);
+                normalise_rows(acc16[2 * mi + 1][0], acc16[2 * mi + 1][1], acc16[2 * mi + 1][2], acc16[2 * mi + 1][3]);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int row0 = m0 + (wm * MI + mi) * 32;
@@ -423,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                         }
                     }
                 }
+            }
             return;
         }
     }
@@ -450,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
             conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
                                       acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l, &cur);
         }
+        VH_CLOCK_EXIT();
     } else {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -520,6 +544,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     }
     k.ksplit = ksplit;
     k.scratch = a.scratch;
+    k.dbg = vh_debug_ptr();
     // chunk-major K order when the input does not stay in the 256 MB Infinity Cache either: with tap-major order each tap's
     // re-read then comes from HBM.  Measured: +7..10 % at 256x256 (0.5-1 GB inputs), +3..4 % at 128x128 (0.27-0.54 GB),
     // +1.6 % at 0.2 GB, -2 % at 67 MB (the per-K-tile pointer selection costs VALU and buys nothing there).
@@ -530,23 +555,21 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : korder_arg) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
-    static const bool m16 = !(getenv("VIVID_CONV_MFMA") && atoi(getenv("VIVID_CONV_MFMA")) == 32);
     const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
-    const bool use16 = m16;
     static const int stagger_env = getenv("VIVID_CONV_STAGGER") ? atoi(getenv("VIVID_CONV_STAGGER")) : -1;
     k.stagger = stagger_env >= 0 ? stagger_env : a.stagger == 1 ? 1 : a.stagger == 2 ? 0 : (cfg == 2 ? 1 : 0);
-    if (a.epi == VH_EPI_QKV && !use16) return vh_fail(VH_EINVAL, "vh_conv: the QKV epilogue exists only in the 16x16x32-MFMA kernels (unset VIVID_CONV_MFMA)");
-    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, use16, grid](hipStream_t s) -> int {
-#define VH_LAUNCH(T, WM, WN, MI_, NI_, M16_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, M16_>), dim3(grid), dim3(512), 0, s, k)
-#define VH_LAUNCH_CFG(T, M16_)                                  \
-        do {                                                    \
-            if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, M16_);       \
-            else if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, M16_);  \
-            else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, M16_);  \
-            else VH_LAUNCH(T, 4, 2, 2, 2, M16_);                \
+    const bool chunk = k.korder != 0;
+    return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, chunk, grid](hipStream_t s) -> int {
+#define VH_LAUNCH(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_>), dim3(grid), dim3(512), 0, s, k)
+#define VH_LAUNCH_CFG(T, CH_)                                  \
+        do {                                                   \
+            if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, CH_);       \
+            else if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, CH_);  \
+            else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, CH_);  \
+            else VH_LAUNCH(T, 4, 2, 2, 2, CH_);                \
         } while (0)
-        if (taps == 9) { if (use16) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
-        else { if (use16) VH_LAUNCH_CFG(1, true); else VH_LAUNCH_CFG(1, false); }
+        if (taps == 9) { if (chunk) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
+        else VH_LAUNCH_CFG(1, false);
 #undef VH_LAUNCH_CFG
 #undef VH_LAUNCH
         if (k.ksplit > 1) {
