@@ -21,7 +21,7 @@ kind = sys.argv[1]
 args = [int(x) for x in sys.argv[2:]]
 L.LIB_PATH = os.path.join(ROOT, "vivid_amd", "libvivid_hip_clkc.so" if kind == "conv" else "libvivid_hip_clka.so")
 ctx = L.Context(torch.cuda.current_stream().cuda_stream)
-dbg = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+dbg = torch.zeros(12 << 14, dtype=torch.int64, device="cuda")
 L.set_knob("dbg_lo", dbg.data_ptr() & 0xFFFFFFFF if (dbg.data_ptr() & 0xFFFFFFFF) < 2 ** 31 else (dbg.data_ptr() & 0xFFFFFFFF) - 2 ** 32)
 L.set_knob("dbg_hi", dbg.data_ptr() >> 32)
 g = torch.Generator().manual_seed(0)
@@ -67,7 +67,7 @@ while time.perf_counter() - t0 < seconds:
     n += 20
     torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-W = 4 if kind == "conv" else 2
+W = 12 if kind == "conv" else 2
 d = dbg.cpu().numpy().reshape(-1, W)
 d = d[d[:, 1] > 0].astype(np.float64)
 ghz = d[:, 0] / d[:, 1] * 0.1
@@ -80,3 +80,5 @@ if kind == "conv":
     per_tile_us = dt / n / wg_per_cu * 1e6
     print(f"  per workgroup: prologue {np.median(d[:, 2]) / clk / 1e3:.2f} us, K loop {np.median(d[:, 0]) / clk / 1e3:.2f} us, epilogue issue {np.median(d[:, 3]) / clk / 1e3:.2f} us; "
           f"launch time / workgroups per CU = {per_tile_us:.2f} us -> unaccounted (store drain, dispatch) {per_tile_us - (np.median(d[:, 0]) + np.median(d[:, 2]) + np.median(d[:, 3])) / clk / 1e3:.2f} us")
+    print("  epilogue, wave 0: cumulative us after each of its 32x32 blocks:", " ".join(f"{np.median(d[:, 4 + b]) / clk / 1e3:.2f}" for b in range(6)))
+    print(f"  prologue, wave 0: index math {np.median(d[:, 10]) / clk / 1e3:.2f} us, first DMA issue + landing {np.median(d[:, 11]) / clk / 1e3:.2f} us")

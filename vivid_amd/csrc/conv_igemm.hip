@@ -279,6 +279,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.out = a.out; k.out_s8 = static_cast<unsigned short*>(a.out_s8); k.out_s8_c = a.out_s8_c; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;
     k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
+    k.div_hw = fastdiv_make((unsigned)(a.h * a.w)); k.div_w = fastdiv_make((unsigned)a.w);
     k.ksplit = 1; k.scratch = nullptr; k.korder = 0; k.stagger = 0; k.dbg = nullptr;
     k.q = nullptr; k.qk = k.qv = nullptr; k.q_heads = k.q_nj = k.q_rows_per_b = k.q_koff = k.q_klp = 0; k.q_d = 64; k.q_scale = 1.f;
     if (a.epi == VH_EPI_QKV) {

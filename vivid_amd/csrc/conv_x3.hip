@@ -15,6 +15,7 @@
 // the image).  Two LDS stages; the loads of tile t+1 are in flight during the MFMAs of tile t.
 #include "conv_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #ifndef VH_EPI_PD
@@ -91,9 +92,13 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         const int gm = m0 + j * 64 + rsub;
         pv[j] = gm < a.M;
         const int g = pv[j] ? gm : 0;
-        const int img = g / a.HW;
+        if (TAPS == 1 && !a.up) {                           // a 1x1 tap reads pixel g itself: no (image, y, x) split (two integer divisions per slot)
+            py[j] = 0; px[j] = g; pbase[j] = 0;
+            continue;
+        }
+        const int img = fastdiv(g, a.div_hw);
         const int rem = g - img * a.HW;
-        py[j] = rem / a.w;
+        py[j] = fastdiv(rem, a.div_w);
         px[j] = rem - py[j] * a.w;
         pbase[j] = img * Hs * Ws;
     }
@@ -117,13 +122,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     if constexpr (CHUNK) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            unsigned m = 0;
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                const int yy = py[j] + tp / 3 - 1, xx = px[j] + tp % 3 - 1;
-                if (pv[j] && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w) m |= 1u << tp;
-            }
-            pmask[j] = m;
+            // tap (dy, dx) is inside the image iff row py+dy and column px+dx are: 3 row bits x 3 column bits instead of 9 x 4 compares
+            const unsigned xm = (px[j] > 0 ? 1u : 0u) | 2u | (px[j] < a.w - 1 ? 4u : 0u);
+            const unsigned ym = (py[j] > 0 ? 1u : 0u) | 2u | (py[j] < a.h - 1 ? 4u : 0u);
+            const unsigned m = ((ym & 1u) ? xm : 0u) | ((ym & 2u) ? xm << 3 : 0u) | ((ym & 4u) ? xm << 6 : 0u);
+            pmask[j] = pv[j] ? m : 0u;
             pc[j] = reinterpret_cast<const float4*>(a.src0 + (size_t)(pbase[j] + py[j] * a.w + px[j]) * a.c0) + u;
         }
     }
@@ -139,6 +142,11 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
             const int ty = tap / 3;
             dy = ty - 1;
             dx = tap - ty * 3 - 1;
+        }
+        if (TAPS == 1 && !a.up) {
+#pragma unroll
+            for (int j = 0; j < RA; ++j) pa[j] = pv[j] ? reinterpret_cast<const float4*>(a.src0 + (size_t)px[j] * a.c0) + u : zp;
+            return;
         }
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
@@ -256,8 +264,17 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     int tap, cc;
     if constexpr (chunk_major) { cc = (kt0 / 9) * BK; tap = kt0 - (kt0 / 9) * 9; setup_tap_fast(tap); }
     else { tap = (kt0 * BK) / a.cin_pad; cc = kt0 * BK - tap * a.cin_pad; setup_tap(tap); }
+#ifdef VH_CLOCK
+    const unsigned long long ck_p1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     issue(0, tap, cc);
     wait_dma();
+#ifdef VH_CLOCK
+    const unsigned long long ck_p2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    if (a.dbg && t == 0) { a.dbg[(size_t)blockIdx.x * 12 + 10] = ck_p1 - ck_e0; a.dbg[(size_t)blockIdx.x * 12 + 11] = ck_p2 - ck_p1; }
+#endif
     __syncthreads();
     // Stagger (MI355X_MICROARCH.md "try a stagger").  s_memtime stamps of this loop (tools/_stamp_conv.py, VH_STAMP build) show that
     // ISSUING the 8-10 DMA pieces of a K-tile costs a wave 1100-1800 cycles against 1536 of MFMA issue, and that when both waves
@@ -320,13 +337,13 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         const unsigned long long ck_m1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);
         if (a.dbg && t == 0) {
-            a.dbg[(size_t)blockIdx.x * 4] = ck_m1 - ck_m0; a.dbg[(size_t)blockIdx.x * 4 + 1] = ck_r1 - ck_r0;
-            a.dbg[(size_t)blockIdx.x * 4 + 2] = ck_m0 - ck_e0;             // prologue: entry -> first K-tile
+            a.dbg[(size_t)blockIdx.x * 12] = ck_m1 - ck_m0; a.dbg[(size_t)blockIdx.x * 12 + 1] = ck_r1 - ck_r0;
+            a.dbg[(size_t)blockIdx.x * 12 + 2] = ck_m0 - ck_e0;             // prologue: entry -> first K-tile
         }
     }
     const unsigned long long ck_l1 = __builtin_amdgcn_s_memtime();
 #define VH_CLOCK_EXIT() do { const unsigned long long ck_x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
-        if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 4 + 3] = ck_x - ck_l1; } while (0)     /* epilogue: instructions issued (stores not drained) */
+        if (a.dbg && t == 0) a.dbg[(size_t)blockIdx.x * 12 + 3] = ck_x - ck_l1; } while (0)     /* epilogue: instructions issued (stores not drained) */
 #else
 #define VH_CLOCK_EXIT()
 #endif
@@ -460,19 +477,40 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         // fragment registers are dead by now, so a few blocks' worth of values fit
         constexpr int NB = MI * NI;
         constexpr int PD = VH_EPI_PD < NB ? VH_EPI_PD : NB;
-        EpiAux ring[PD];
+        // Blocks wholly inside the output take the branch-free read-out specialised on the epilogue kind (conv_epilogue_block_fast);
+        // edge blocks (ragged M or Cout) and unaligned channel counts keep the generic one.  Both are wave-uniform choices.
+        const bool fast_ok = (e.cout & 3) == 0 && (e.epi != VH_EPI_SCALE_SILU || (e.cvec_ld & 3) == 0);
+        auto run = [&](auto epic) __attribute__((always_inline)) {
+            constexpr int EPI = decltype(epic)::value;
+            auto inside = [&](int b) { return fast_ok && m0 + (wm * MI + b / NI) * 32 + 32 <= e.M && n0 + (wn * NI + b % NI) * 32 + 32 <= e.cout; };
+            auto prefetch = [&](int b) __attribute__((always_inline)) {
+                const int r0 = m0 + (wm * MI + b / NI) * 32, c0 = n0 + (wn * NI + b % NI) * 32;
+                return inside(b) ? conv_epilogue_prefetch_fast<EPI>(e, r0, c0, l) : conv_epilogue_prefetch(e, r0, c0, l);
+            };
+            EpiAux ring[PD];
 #pragma unroll
-        for (int b = 0; b < PD; ++b)
-            ring[b] = conv_epilogue_prefetch(e, m0 + (wm * MI + b / NI) * 32, n0 + (wn * NI + b % NI) * 32, l);
+            for (int b = 0; b < PD; ++b) ring[b] = prefetch(b);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int mi = b / NI, ni = b % NI;
-            const EpiAux cur = ring[b % PD];
-            if (b + PD < NB)
-                ring[b % PD] = conv_epilogue_prefetch(e, m0 + (wm * MI + (b + PD) / NI) * 32, n0 + (wn * NI + (b + PD) % NI) * 32, l);
-            conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
-                                      acc16[2 * mi + 1][2 * ni + 1], m0 + (wm * MI + mi) * 32, n0 + (wn * NI + ni) * 32, patch, l, &cur);
-        }
+            for (int b = 0; b < NB; ++b) {
+                const int mi = b / NI, ni = b % NI;
+                const EpiAux cur = ring[b % PD];
+                if (b + PD < NB) ring[b % PD] = prefetch(b + PD);
+                const int r0 = m0 + (wm * MI + mi) * 32, c0 = n0 + (wn * NI + ni) * 32;
+                if (inside(b))
+                    conv_epilogue_block_fast<EPI>(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
+                                                  acc16[2 * mi + 1][2 * ni + 1], r0, c0, patch, l, cur);
+                else
+                    conv_epilogue_tiles16_lds(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
+                                              acc16[2 * mi + 1][2 * ni + 1], r0, c0, patch, l, &cur);
+#ifdef VH_CLOCK
+                if (a.dbg && t == 0 && b < 6) { const unsigned long long ck_b = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F);
+                                                a.dbg[(size_t)blockIdx.x * 12 + 4 + b] = ck_b - ck_l1; }
+#endif
+            }
+        };
+        if (e.epi == VH_EPI_MPSUM) run(std::integral_constant<int, VH_EPI_MPSUM>{});
+        else if (e.epi == VH_EPI_SCALE_SILU) run(std::integral_constant<int, VH_EPI_SCALE_SILU>{});
+        else run(std::integral_constant<int, VH_EPI_STORE>{});
         VH_CLOCK_EXIT();
     } else {
 #pragma unroll
