@@ -34,13 +34,11 @@ constexpr int BK = 32;
 // that publishes the stage (cdna_hip_programming.md 5.7: M0 carries the LDS address and is saved/restored inside
 // the statement).  Compiled in the device pass only (a templated __global__ function that contains the builtin
 // or this asm directly gets no host launch stub from hipcc).
-__device__ __forceinline__ void glds16(const float4* gsrc, float4* lds_wave_base) {
+__device__ __forceinline__ void glds16(const float4* gsrc, unsigned lds_addr) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const unsigned lds = __builtin_amdgcn_readfirstlane(
-        (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds) : "memory");
+    // lds_addr: wave-uniform LDS byte address, already in a scalar register (the caller derives it from one readfirstlane per
+    // kernel); M0 is declared clobbered instead of saved and restored (nothing else in these kernels uses it)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "memory", "m0");
 #endif
 }
 
@@ -157,16 +155,23 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         }
     };
 
+    // this wave's LDS destinations as scalar byte addresses (one readfirstlane each; the stage and round offsets are scalar adds)
+    unsigned ldsA_w = 0, ldsB_w = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    ldsA_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sA[0][w * 64]);
+    ldsB_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sB[0][w * 64]);
+#endif
     // issue the DMA of one K-tile (cc = channel offset inside the tap) into LDS stage `st`
     auto issue = [&](int st, int tap, int cc) {
         const int cu = cc >> 2;                            // channel offset in 16-byte units
         const int bu = (tap * a.cin_pad + cc) >> 2;        // K offset of the weight tile, same units
+        const unsigned la = ldsA_w + (unsigned)st * (unsigned)(BM * 8 * 16), lb = ldsB_w + (unsigned)st * (unsigned)(BN * 8 * 16);
 #pragma unroll
         for (int j = 0; j < RA; ++j)
-            glds16(pa[j] + cu, &sA[st][j * 512 + w * 64]);
+            glds16(pa[j] + cu, la + j * 8192u);            // LDS slot (round j, wave w): float4 index j*512 + w*64
 #pragma unroll
         for (int j = 0; j < RB; ++j)
-            glds16(bzero[j] ? zp : pb[j] + bu, &sB[st][j * 512 + w * 64]);
+            glds16(bzero[j] ? zp : pb[j] + bu, lb + j * 8192u);
     };
 
     f32x16 acc[M16 ? 1 : MI][M16 ? 1 : NI];
@@ -276,13 +281,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     if (a.dbg && t == 0) { a.dbg[(size_t)blockIdx.x * 12 + 10] = ck_p1 - ck_e0; a.dbg[(size_t)blockIdx.x * 12 + 11] = ck_p2 - ck_p1; }
 #endif
     __syncthreads();
-    // Stagger (MI355X_MICROARCH.md "try a stagger").  s_memtime stamps of this loop (tools/_stamp_conv.py, VH_STAMP build) show that
-    // ISSUING the 8-10 DMA pieces of a K-tile costs a wave 1100-1800 cycles against 1536 of MFMA issue, and that when both waves
-    // of a SIMD do it right after the barrier the matrix pipe idles meanwhile.  With `stagger`, waves 0-3 fetch tile kt+1 before
-    // their MFMAs and their SIMD partners 4-7 between the two halves of theirs, so one wave's DMA issue runs under the other's
-    // matrix work (stage st^1 is free for the whole K-tile either way).  On for the 512x128 tile (+3..6 % on every device tried); for
-    // the 256-row tiles the sign depends on the device (+6..9 % on one MI355X, -1.5..3 % on two others, repeated A/B each), so
-    // they keep the plain order.  Issuing after ALL of the late waves' MFMAs instead is worse everywhere.
+    // Stagger (vh_conv_args.stagger = 1; MI355X_MICROARCH.md "try a stagger"): waves 0-3 fetch tile kt+1 before their MFMAs and their
+    // SIMD partners 4-7 between the two halves of theirs, so that one wave's DMA issue runs under the other's matrix work.  Round 1
+    // shipped it for the 512x128 tile (+3..6 % there with the DMA issue as it then was: ~120 cycles per piece).  With the lean issue
+    // (scalar LDS addresses, no M0 save/restore: ~70 cycles per piece) and the short epilogue, same-device A/B of round 2 has the plain
+    // order ahead on every tile shape (512x128: 1.06-1.07x vs 0.97-1.02x staggered; 256-row tiles: staggered -6..-20 %), so the
+    // default is off everywhere; the hint stays in the ABI (results are bit-identical either way).
     const bool late = a.stagger && w >= 4;
 #ifdef VH_STAMP   // diagnostic build (`make stamp`, tools/stamp_conv.py): shader-cycle stamps around the segments of a K-tile, per wave
     unsigned long long tacc[4] = {0, 0, 0, 0};
@@ -595,7 +599,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const int taps = a.taps;
     const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
     static const int stagger_env = getenv("VIVID_CONV_STAGGER") ? atoi(getenv("VIVID_CONV_STAGGER")) : -1;
-    k.stagger = stagger_env >= 0 ? stagger_env : a.stagger == 1 ? 1 : a.stagger == 2 ? 0 : (cfg == 2 ? 1 : 0);
+    k.stagger = stagger_env >= 0 ? stagger_env : (a.stagger == 1 ? 1 : 0);       // default: off (see the kernel's note on `late`)
     const bool chunk = k.korder != 0;
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, chunk, grid](hipStream_t s) -> int {
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_>), dim3(grid), dim3(512), 0, s, k)
