@@ -288,26 +288,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     // order ahead on every tile shape (512x128: 1.06-1.07x vs 0.97-1.02x staggered; 256-row tiles: staggered -6..-20 %), so the
     // default is off everywhere; the hint stays in the ABI (results are bit-identical either way).
     const bool late = a.stagger && w >= 4;
-#ifdef VH_STAMP   // diagnostic build (`make stamp`, tools/stamp_conv.py): shader-cycle stamps around the segments of a K-tile, per wave
-    unsigned long long tacc[4] = {0, 0, 0, 0};
-    auto stamp = [&]() -> unsigned long long {
-        unsigned long long t_;
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        return t_;
-    };
-#define VH_STAMP_AT(v) const unsigned long long v = stamp()
-#else
-#define VH_STAMP_AT(v)
-#endif
 #ifdef VH_CLOCK   // diagnostic build: shader clock (s_memtime) against the 100 MHz reference (s_memrealtime) around the K loop
     unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
     for (int kt = 0; kt < KT; ++kt) {
         const int st = kt & 1;
-        VH_STAMP_AT(s0);
         auto fetch_next = [&]() {
             if (kt + 1 < KT) {
                 if constexpr (chunk_major) {
@@ -325,16 +311,9 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
             }
         };
         if (!late) fetch_next();
-        VH_STAMP_AT(s1);
         compute(st, [&]() { if (late) fetch_next(); });
-        VH_STAMP_AT(s2);
         wait_dma();                                        // this wave's DMA of tile kt+1 has landed ...
-        VH_STAMP_AT(s3);
         __syncthreads();                                   // ... and so has every other wave's
-        VH_STAMP_AT(s4);
-#ifdef VH_STAMP
-        tacc[0] += s1 - s0; tacc[1] += s2 - s1; tacc[2] += s3 - s2; tacc[3] += s4 - s3;
-#endif
     }
 #ifdef VH_CLOCK
     {
@@ -351,14 +330,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
 #else
 #define VH_CLOCK_EXIT()
 #endif
-#ifdef VH_STAMP   // stamps go to the split-K scratch (unused when ksplit == 1), never into an output
-    if (a.scratch && a.ksplit == 1 && l == 0) {
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.scratch) + ((size_t)blockIdx.x * 8 + w) * 6;
-        dbg[0] = tacc[0]; dbg[1] = tacc[1]; dbg[2] = tacc[2]; dbg[3] = tacc[3]; dbg[4] = (unsigned long long)KT; dbg[5] = 0;
-    }
-#endif
-#undef VH_STAMP_AT
-
     // the loop's last barrier has retired every read of the stages: reuse sA as 8 per-wave transpose patches
     float* patch = reinterpret_cast<float*>(&sA[0][0]) + w * (32 * 36);
     if constexpr (TAPS == 1 && M16 && NI == 2) {
