@@ -81,12 +81,15 @@ def main():
             ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin, k_pad=k_pad, gain_ptr=None,
                                                         gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2))
             out = torch.empty(M, cout, device="cuda")
+            s8mode = knobs.pop("s8", 0)                     # 0: fp32 output, 1: S8 only, 2: both
+            o8 = torch.empty(M * cout, device="cuda") if s8mode else None
             a = L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=taps, pro=0,
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
-                           scratch_floats=scr.numel(), cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=epi,
+                           scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if s8mode != 1 else None, out_s8=o8.data_ptr() if o8 is not None else None,
+                           out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,
                            cvec=None, cvec_ld=0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
                            korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0))
-            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, out)))
+            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, o8 if s8mode == 1 else out)))
 
     def launch(r, k):
         name, ctx, op, a, knobs, _ = r
