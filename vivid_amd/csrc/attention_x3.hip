@@ -322,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     constexpr int KU = D / 4;
     constexpr int K_UNITS = KU * KT, V_UNITS = D * 2 * (KT / 8);
     __shared__ uint4 sK[3][K_UNITS];
-    __shared__ uint4 sV[2][V_UNITS];
+    __shared__ uint4 sV[VH_ATTN_STATIC_SLOTS ? 3 : 2][V_UNITS];   // (static-slot build: V ring of 3 as well, so that the slot pattern repeats every 3 tiles)
 
     const int t = threadIdx.x;
     const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
@@ -530,11 +530,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         for (int r = 0; r < 16; ++r) { scur[r] -= mx; negm[r] = -mx; }
     }
 
-    // One tile with its LDS slots as compile-time constants: K slots of tiles t, t+1, t+2 are (t, t+1, t+2) mod 3, the V slot t mod 2,
-    // so the pattern repeats every 6 tiles and the loop dispatches on t mod 6.  With run-time slot numbers every ds_read address
+    // One tile with its LDS slots as compile-time constants: K slots of tiles t, t+1, t+2 are (t, t+1, t+2) mod 3 and (V ring of 3) the
+    // V slot t mod 3, so the pattern repeats every 3 tiles and the loop dispatches on t mod 3.  With run-time slot numbers every ds_read address
     // was rebuilt per step (12 v_lshl_add + 7 v_or of ~100 VALU per 24 MFMAs, in a loop whose limiter is VALU issue).
-    auto one_tile = [&](auto k0c, auto k1c, auto k2c, auto vc, int tile) __attribute__((always_inline)) {
-        constexpr int KS0 = decltype(k0c)::value, KS1 = decltype(k1c)::value, KS2 = decltype(k2c)::value, VS = decltype(vc)::value;
+    auto one_tile = [&](auto k0c, auto k1c, auto k2c, int tile) __attribute__((always_inline)) {
+        constexpr int KS0 = decltype(k0c)::value, KS1 = decltype(k1c)::value, KS2 = decltype(k2c)::value;
+        constexpr int VS = KS0, VS1 = KS1;                  // V ring of 3: tile t's values in slot t mod 3, like its keys
         const int k0 = tile * KT;
         const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
         if (more2) loadK();
@@ -542,26 +543,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         step(VS, 0, KS0, 1, k0, is_tail(tile));
         step(VS, 1, KS1, 0, k0 + KT, is_tail(tile + 1));
         if (more2) storeK(KS2, k0 + 2 * KT, is_tail(tile + 2));
-        if (more1) storeV(VS ^ 1, k0 + KT, is_tail(tile + 1));
+        if (more1) storeV(VS1, k0 + KT, is_tail(tile + 1));
         __syncthreads();
     };
-#ifdef VH_CLOCK
-    unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#endif
 #if VH_ATTN_STATIC_SLOTS
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     int phase = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
-        switch (phase) {
-            case 0: one_tile(I0{}, I1{}, I2{}, I0{}, tile); break;
-            case 1: one_tile(I1{}, I2{}, I0{}, I1{}, tile); break;
-            case 2: one_tile(I2{}, I0{}, I1{}, I0{}, tile); break;
-            case 3: one_tile(I0{}, I1{}, I2{}, I1{}, tile); break;
-            case 4: one_tile(I1{}, I2{}, I0{}, I0{}, tile); break;
-            default: one_tile(I2{}, I0{}, I1{}, I1{}, tile); break;
-        }
-        phase = phase == 5 ? 0 : phase + 1;
+        if (phase == 0) one_tile(I0{}, I1{}, I2{}, tile);
+        else if (phase == 1) one_tile(I1{}, I2{}, I0{}, tile);
+        else one_tile(I2{}, I0{}, I1{}, tile);
+        phase = phase == 2 ? 0 : phase + 1;
     }
 #else   // run-time slot numbers (A/B reference)
     (void)one_tile;
