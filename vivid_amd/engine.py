@@ -125,8 +125,8 @@ class Engine:
         # 377.4 ms at the headline workload: replay is GPU-bound, not launch-bound), so opt-in only
         self.use_graph = os.environ.get("VIVID_HIPGRAPH", "0") == "1"
         self.conv_stagger = 0                 # vh_conv scheduling hint: 0 = library default (the 512x128 tile staggers, the others do not)
-        # attn_qkv / x_attn_kv write q, k, v^T from their own epilogue (needs the 16x16x32-MFMA glds kernel)
-        self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0" and os.environ.get("VIVID_CONV_MFMA", "16") != "32"
+        # attn_qkv / x_attn_kv write q, k, v^T from their own epilogue (glds kernel)
+        self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0"
         self.cfg = cfg
         self.std_filter = tuple(float(v) for v in cfg.resample_filter) == (1.0, 1.0)
         self.dual = dual_source
