@@ -379,21 +379,21 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                     const bool is_q = a.q_nj == 3 && j == 0, is_k = a.q_nj == 3 ? j == 1 : j == 0;
                     const int dbase = D == 64 ? ni * 32 : 0;                // first head channel of this block
                     constexpr int LD = 36;
-                    {
-                        const int c = l & 15, rb = (l >> 4) * 4;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            patch[(rb + r) * LD + c] = acc16[2 * mi][2 * ni][r];
-                            patch[(rb + r) * LD + 16 + c] = acc16[2 * mi][2 * ni + 1][r];
-                            patch[(16 + rb + r) * LD + c] = acc16[2 * mi + 1][2 * ni][r];
-                            patch[(16 + rb + r) * LD + 16 + c] = acc16[2 * mi + 1][2 * ni + 1][r];
-                        }
-                    }
-                    const int rowi = row0 / S, s0 = row0 - rowi * S;           // 32 | S: the block lies inside one image
+                    const int rowi = fastdiv(row0, a.div_hw), s0 = row0 - rowi * S;   // 32 | S: the block lies inside one image
                     const int bb = rowi / a.q_rows_per_b, seg = rowi - bb * a.q_rows_per_b;
                     const size_t bhq = (size_t)bb * a.q_heads + head;
                     const int key0 = a.q_koff + seg * S + s0;                  // multiple of 16
                     if (is_q || is_k) {
+                        {
+                            const int c = l & 15, rb = (l >> 4) * 4;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                patch[(rb + r) * LD + c] = acc16[2 * mi][2 * ni][r];
+                                patch[(rb + r) * LD + 16 + c] = acc16[2 * mi][2 * ni + 1][r];
+                                patch[(16 + rb + r) * LD + c] = acc16[2 * mi + 1][2 * ni][r];
+                                patch[(16 + rb + r) * LD + 16 + c] = acc16[2 * mi + 1][2 * ni + 1][r];
+                            }
+                        }
                         const int cg = l & 7, rsub = l >> 3;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -416,25 +416,27 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                             }
                         }
                     } else {
-                        // V^T [bh][d][hl][klp], positions permuted inside 16-key groups (bits 2,3 swapped): lane = channel c and
-                        // half the block's 4 units of 8 positions
-                        const int c = l & 31, d = dbase + c;
+                        // V^T [bh][d][hl][klp], positions permuted inside 16-key groups (bits 2,3 swapped).  Straight from the
+                        // accumulators: in the C/D map of the 16x16 MFMA a lane already holds 4 consecutive keys (rows 4q..4q+3,
+                        // q = lane>>4) of one channel (column lane&15), and the permutation keeps those four together at positions
+                        // 4*((q&1)*2 + (q>>1)) - one 8-byte store per tile and half, no LDS transpose.
+                        const int q4 = l >> 4, qs = ((q4 & 1) << 1) | (q4 >> 1);
 #pragma unroll
-                        for (int uu = 0; uu < 2; ++uu) {
-                            const int unit = (l >> 5) * 2 + uu;                // 8 positions 8*unit .. of the 32-key block
-                            unsigned h[8], lo[8];
+                        for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
-                            for (int e2 = 0; e2 < 8; ++e2) {
-                                const int pos = unit * 8 + e2;
-                                const int key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
-                                const float y = patch[key * LD + c];
-                                h[e2] = bf16_rn_bits(y);
-                                lo[e2] = bf16_rn_bits(y - __uint_as_float(h[e2] << 16));
+                            for (int tb = 0; tb < 2; ++tb) {
+                                const f32x4 tv = acc16[2 * mi + ta][2 * ni + tb];
+                                unsigned h[4], lo[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    h[r] = bf16_rn_bits(tv[r]);
+                                    lo[r] = bf16_rn_bits(tv[r] - __uint_as_float(h[r] << 16));
+                                }
+                                const int d = dbase + 16 * tb + (l & 15);
+                                unsigned short* vp = a.qv + ((bhq * D + d) * 2) * (size_t)a.q_klp + key0 + 16 * ta + 4 * qs;
+                                *reinterpret_cast<uint2*>(vp) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                                *reinterpret_cast<uint2*>(vp + a.q_klp) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
                             }
-                            unsigned short* vp = a.qv + ((bhq * D + d) * 2) * (size_t)a.q_klp + key0 + unit * 8;
-                            *reinterpret_cast<uint4*>(vp) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-                            *reinterpret_cast<uint4*>(vp + a.q_klp) = make_uint4(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16), lo[4] | (lo[5] << 16), lo[6] | (lo[7] << 16));
-                        }
                     }
                 }
             }
