@@ -18,6 +18,13 @@
 #include <type_traits>
 #include <cstdlib>
 
+// The Makefile builds this file twice: VH_CONV_TU=9 (the 3x3 kernels, the split-K reducer and the dispatcher; compiled with
+// -mllvm -amdgpu-sched-strategy=iterative-ilp, +2.0..2.8 % on the 3x3 shapes of C2) and VH_CONV_TU=1 (the 1x1 kernels, default
+// scheduler: iterative-ilp costs them 2 %).  0 = everything in one object (tools' variant builds).
+#ifndef VH_CONV_TU
+#define VH_CONV_TU 0
+#endif
+
 #ifndef VH_EPI_PD
 #define VH_EPI_PD 1          // epilogue blocks whose residual / cvec values are in flight ahead of the one being written (3 measured the same)
 #endif
@@ -498,6 +505,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     }
 }
 
+#if VH_CONV_TU != 1
 // split-K reducer: sums the ksplit partial-sum slabs and applies the epilogue; one thread per 4 output channels
 __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long long total4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -520,8 +528,27 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long lo
     conv_epilogue_vec4(a, gm, gn, y);
 }
 
+#endif
+
 }  // namespace
 
+#define VH_LAUNCH(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_>), dim3(grid), dim3(512), 0, s, k)
+#define VH_LAUNCH_CFG(T, CH_)                                  \
+    do {                                                       \
+        if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, CH_);           \
+        else if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, CH_);      \
+        else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, CH_);      \
+        else VH_LAUNCH(T, 4, 2, 2, 2, CH_);                    \
+    } while (0)
+
+// cfg: 0 = 256x128 tile, 1 = 256x256, 2 = 512x128, 3 = 512x64
+#if VH_CONV_TU != 9
+void vh_conv_x3_launch_1tap(const vhconv::ConvK& k, int cfg, unsigned grid, hipStream_t s) { VH_LAUNCH_CFG(1, false); }
+#else
+void vh_conv_x3_launch_1tap(const vhconv::ConvK& k, int cfg, unsigned grid, hipStream_t s);
+#endif
+
+#if VH_CONV_TU != 1
 // Entry used by vh_conv for prec == VH_PREC_BF16X3 && kernel == VH_CONV_GLDS (arguments already validated).
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
@@ -575,18 +602,8 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     k.stagger = stagger_env >= 0 ? stagger_env : (a.stagger == 1 ? 1 : 0);       // default: off (see the kernel's note on `late`)
     const bool chunk = k.korder != 0;
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, chunk, grid](hipStream_t s) -> int {
-#define VH_LAUNCH(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_>), dim3(grid), dim3(512), 0, s, k)
-#define VH_LAUNCH_CFG(T, CH_)                                  \
-        do {                                                   \
-            if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, CH_);       \
-            else if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, CH_);  \
-            else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, CH_);  \
-            else VH_LAUNCH(T, 4, 2, 2, 2, CH_);                \
-        } while (0)
         if (taps == 9) { if (chunk) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
-        else VH_LAUNCH_CFG(1, false);
-#undef VH_LAUNCH_CFG
-#undef VH_LAUNCH
+        else vh_conv_x3_launch_1tap(k, cfg, grid, s);
         if (k.ksplit > 1) {
             const long long total4 = (long long)k.M * ((k.cout + 3) / 4);
             hipLaunchKernelGGL(conv_splitk_reduce, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, k, total4);
@@ -594,3 +611,4 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         return vh_check_launch("conv_x3_glds");
     });
 }
+#endif  // VH_CONV_TU != 1
