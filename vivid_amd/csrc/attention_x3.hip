@@ -31,6 +31,13 @@ constexpr float RESCALE_THR = 8.0f;
 #define VH_ATTN_STATIC_SLOTS 0     // 1: compile-time LDS slot numbers in the pipelined kernel (6-phase loop): 20 % fewer VALU instructions, measured 10 % SLOWER
 #endif
 
+#ifndef VH_ATTN_PRIO
+#define VH_ATTN_PRIO 0
+#endif
+#ifndef VH_ATTN_PLACED
+#define VH_ATTN_PLACED 1           // hand-placed three-stage step for D = 64 without running maximum (0: compiler-scheduled two-stage step, the A/B reference)
+#endif
+
 struct AttnXK {
     const float* q; const uint4* k; const uint4* vt; float* out;
     int heads, s, kl, klp, c;
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     constexpr int KU = D / 4;
     constexpr int K_UNITS = KU * KT, V_UNITS = D * 2 * (KT / 8);
     __shared__ uint4 sK[3][K_UNITS];
-    __shared__ uint4 sV[VH_ATTN_STATIC_SLOTS ? 3 : 2][V_UNITS];   // (static-slot build: V ring of 3 as well, so that the slot pattern repeats every 3 tiles)
+    constexpr bool PLACED = VH_ATTN_PLACED && NOMAX && D == 64;     // the hand-placed three-stage step (below)
+    __shared__ uint4 sV[(VH_ATTN_STATIC_SLOTS || PLACED) ? 3 : 2][V_UNITS];   // (placed: a tile's values are still read one step into the next tile; static-slot build: pattern repeats every 3 tiles)
 
     const int t = threadIdx.x;
     const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
@@ -514,9 +522,162 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         scur = snext;
     };
 
+    // ---- hand-placed three-stage step (D = 64, no running maximum) ------------------------------------------------------
+    // Two waves share a SIMD's matrix pipe and its vector issue port.  Per step a wave has 24 MFMAs (32 pipe cycles each, 8 of them
+    // on the port) and ~90 VALU instructions (4 cycles of the port each, exp2 8): the pair needs 2 x (192 + ~400) port cycles against
+    // 2 x 768 pipe cycles, so the pipe can only stay busy if EVERY MFMA gap carries its ~1/24 share of the VALU work - a gap with 7
+    // VALU beside each of the two waves' MFMAs is port-bound (measured: the two-stage placed form, all softmax work beside the
+    // QK^T MFMAs, gained 1 %).  A uniform spread needs the softmax to be independent of BOTH MFMA groups of its step, hence three
+    // stages: step i issues QK^T of sub-tile i+1, exp2 / row sum / hi-lo split of sub-tile i, and P.V of sub-tile i-1 (P carried one
+    // step in registers, V ring of 3 slots because a tile's values are read one step into the next tile).  The step is written as
+    // 24 scheduling regions (sched_barrier(0): nothing moves across) of one MFMA + one third of a logit pair's softmax; LDS
+    // fragments are read 3+ regions before their MFMA, the first K fragments of the next step in this step's tail (kpre_*).
+    // Row sums stay per lane half (two running sums); the cross-half add happens once, after the key loop.
+    bf16x8 kpre_h, kpre_l;
+    // per-lane LDS byte addresses of the fragments in slot 0 (K: sub-tile 0; V: d < 32).  Slot, K sub-tile and d >= 32 are compile-time
+    // in the placed loop (it is unrolled over the three ring positions), so they become the ds_read's immediate offset and a fragment
+    // address costs no VALU at all (index form: v_or + v_lshl_add per address, ~20 of ~105 VALU per step)
+    unsigned koff[D / 16][2], voff[2][2][2];                 // [slab][hi, lo]; [keys 0-31 / 32-63 of the tile][16-key half][hi, lo]
+    {
+        const unsigned kbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sK[0][0];
+        const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sV[0][0];
+#pragma unroll
+        for (int sl = 0; sl < D / 16; ++sl)
+#pragma unroll
+            for (int lohi = 0; lohi < 2; ++lohi) {
+                const int u = (sl * 2 + hh) * 2 + lohi;
+                koff[sl][lohi] = kbase + (unsigned)(u * KT + (lr ^ (u & 7))) * 16u;
+                asm("" : "+v"(koff[sl][lohi]));
+                koff[sl][lohi] &= 0x3ffffu;              // (known-positive base: lets the slot / sub-tile constant fold into the ds_read offset field)
+            }
+#pragma unroll
+        for (int vks = 0; vks < 2; ++vks)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int lohi = 0; lohi < 2; ++lohi) {
+                    const int kuh = vks * 4 + s2 * 2 + hh;
+                    voff[vks][s2][lohi] = vbase + (unsigned)(lr * 16 + ((lohi * 8 + kuh) ^ (lr & 15))) * 16u;
+                    asm("" : "+v"(voff[vks][s2][lohi]));
+                    voff[vks][s2][lohi] &= 0x3ffffu;
+                }
+    }
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+    auto kfrag = [&](int slot, int ks, int sl, int lohi) __attribute__((always_inline)) -> bf16x8 {
+        return *(lds_frag_ptr)(size_t)(koff[sl][lohi] + (unsigned)(slot * (K_UNITS * 16) + ks * 512));
+    };
+    auto vfrag = [&](int slot, int vks, int s2, int dt, int lohi) __attribute__((always_inline)) -> bf16x8 {
+        return *(lds_frag_ptr)(size_t)(voff[vks][s2][lohi] + (unsigned)(slot * (V_UNITS * 16) + dt * 8192));
+    };
+#define VH_SB() __builtin_amdgcn_sched_barrier(0)
+#define VH_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+#define VH_MFMA_O(a_, b_, c_) c_ = VH_MFMA(a_, b_, c_)
+    float lsum0 = 0.f, lsum1 = 0.f;
+    // pin / pout: {hi keys 0-15, lo keys 0-15, hi keys 16-31, lo keys 16-31} of the previous / this sub-tile's P
+    auto step3 = [&](int vslot, int vks, int nslot, int nks, int nk0, bool ntail, int pslot, int pks,
+                     const bf16x8 (&pin)[4], bf16x8 (&pout)[4]) __attribute__((always_inline)) {
+      if constexpr (D == 64) {
+        float e[16];
+        unsigned hw[8], lw[8];
+        float t0[8], t1[8];
+        auto cvt2 = [](float x, float y) __attribute__((always_inline)) -> unsigned {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 v; v[0] = (__bf16)x; v[1] = (__bf16)y;                // one v_cvt_pk_bf16_f32
+            unsigned r = __builtin_bit_cast(unsigned, v);
+            asm("" : "+v"(r));                                           // opaque: hipcc otherwise converts x a second time on its own for x - hi(x)
+            return r;
+        };
+        // one logit pair = 10 VALU in three pieces
+        auto EA = [&](int p) __attribute__((always_inline)) {          // 2 exp2
+            e[2 * p] = __builtin_amdgcn_exp2f(scur[2 * p]); e[2 * p + 1] = __builtin_amdgcn_exp2f(scur[2 * p + 1]);
+        };
+        auto EB = [&](int p) __attribute__((always_inline)) {          // 5 VALU
+            hw[p] = cvt2(e[2 * p], e[2 * p + 1]);
+            lsum0 += e[2 * p]; lsum1 += e[2 * p + 1];
+            t0[p] = __uint_as_float(hw[p] << 16); t1[p] = __uint_as_float(hw[p] & 0xffff0000u);
+        };
+        auto EC = [&](int p) __attribute__((always_inline)) {          // 3 VALU
+            lw[p] = cvt2(e[2 * p] - t0[p], e[2 * p + 1] - t1[p]);
+        };
+        auto frag4 = [](unsigned a0, unsigned a1, unsigned a2, unsigned a3) __attribute__((always_inline)) -> bf16x8 {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v = {a0, a1, a2, a3};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        // 1
+        const bf16x8 k1l = kfrag(nslot, nks, 1, 1), k1h = kfrag(nslot, nks, 1, 0);
+        const bf16x8 v00l = vfrag(vslot, vks, 0, 0, 1), v00h = vfrag(vslot, vks, 0, 0, 0);
+        snext = VH_MFMA(kpre_l, qh[0], z); EA(0); VH_SB();
+        snext = VH_MFMA(kpre_h, ql[0], snext); EB(0); VH_SB();
+        snext = VH_MFMA(kpre_h, qh[0], snext); EC(0); VH_SB();
+        // 4
+        const bf16x8 k2l = kfrag(nslot, nks, 2, 1), k2h = kfrag(nslot, nks, 2, 0);
+        VH_MFMA_O(v00l, pin[0], oacc[0]); EA(1); VH_SB();
+        snext = VH_MFMA(k1l, qh[1], snext); EB(1); VH_SB();
+        const bf16x8 v01l = vfrag(vslot, vks, 0, 1, 1), v01h = vfrag(vslot, vks, 0, 1, 0);
+        VH_MFMA_O(v00h, pin[1], oacc[0]); EC(1); VH_SB();
+        // 7
+        snext = VH_MFMA(k1h, ql[1], snext); EA(2); VH_SB();
+        VH_MFMA_O(v00h, pin[0], oacc[0]); EB(2); VH_SB();
+        const bf16x8 k3l = kfrag(nslot, nks, 3, 1), k3h = kfrag(nslot, nks, 3, 0);
+        snext = VH_MFMA(k1h, qh[1], snext); EC(2); VH_SB();
+        // 10
+        VH_MFMA_O(v01l, pin[0], oacc[1]); EA(3); VH_SB();
+        const bf16x8 v10l = vfrag(vslot, vks, 1, 0, 1), v10h = vfrag(vslot, vks, 1, 0, 0);
+        snext = VH_MFMA(k2l, qh[2], snext); EB(3); VH_SB();
+        VH_MFMA_O(v01h, pin[1], oacc[1]); EC(3); VH_SB();
+        // 13
+        snext = VH_MFMA(k2h, ql[2], snext); EA(4); VH_SB();
+        VH_MFMA_O(v01h, pin[0], oacc[1]); EB(4); VH_SB();
+        const bf16x8 v11l = vfrag(vslot, vks, 1, 1, 1), v11h = vfrag(vslot, vks, 1, 1, 0);
+        snext = VH_MFMA(k2h, qh[2], snext); EC(4); VH_SB();
+        // 16
+        VH_MFMA_O(v10l, pin[2], oacc[0]); EA(5); VH_SB();
+        snext = VH_MFMA(k3l, qh[3], snext); EB(5); VH_SB();
+        VH_MFMA_O(v10h, pin[3], oacc[0]); EC(5); VH_SB();
+        // 19
+        snext = VH_MFMA(k3h, ql[3], snext); EA(6); VH_SB();
+        kpre_l = kfrag(pslot, pks, 0, 1); kpre_h = kfrag(pslot, pks, 0, 0);
+        VH_MFMA_O(v10h, pin[2], oacc[0]); EB(6); VH_SB();
+        snext = VH_MFMA(k3h, qh[3], snext); EC(6); VH_SB();
+        // 22
+        VH_MFMA_O(v11l, pin[2], oacc[1]); EA(7); VH_SB();
+        VH_MFMA_O(v11h, pin[3], oacc[1]); EB(7); VH_SB();
+        VH_MFMA_O(v11h, pin[2], oacc[1]); EC(7); VH_SB();
+        // (the row sums are needed only after the loop and hipcc sinks their adds into the loop's last block, keeping all 32 exp2
+        //  results alive until then; one volatile use per step keeps them in this block, where the sched_barriers hold them in place)
+        asm volatile("" : "+v"(lsum0), "+v"(lsum1));
+        pout[0] = frag4(hw[0], hw[1], hw[2], hw[3]); pout[1] = frag4(lw[0], lw[1], lw[2], lw[3]);
+        pout[2] = frag4(hw[4], hw[5], hw[6], hw[7]); pout[3] = frag4(lw[4], lw[5], lw[6], lw[7]);
+        if (ntail) mask_tail(snext, nk0, nks);
+        scur = snext;
+      }
+    };
+    // P.V of the last sub-tile (its P is still in registers when the key loop ends)
+    auto drain3 = [&](int vslot, int vks, const bf16x8 (&pin)[4]) __attribute__((always_inline)) {
+      if constexpr (D == 64) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const bf16x8 vl = vfrag(vslot, vks, s2, dt, 1), vh = vfrag(vslot, vks, s2, dt, 0);
+                VH_MFMA_O(vl, pin[2 * s2], oacc[dt]);
+                VH_MFMA_O(vh, pin[2 * s2 + 1], oacc[dt]);
+                VH_MFMA_O(vh, pin[2 * s2], oacc[dt]);
+            }
+      }
+    };
+
     // prologue: K[0], V[0], K[1] in LDS; logits of sub-tile 0
     loadK(); loadV();
     storeK(0, 0, is_tail(0)); storeV(0, 0, is_tail(0));
+    if constexpr (PLACED) {                                  // the first step multiplies P = 0 with "tile -1": that slot must hold finite numbers
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) sV[2][vsl[i]] = zero4;
+    }
     if (ntiles > 1) { loadK(); storeK(1, KT, is_tail(1)); }
     __syncthreads();
     qk(scur, 0, 0);
@@ -558,6 +719,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 #else   // run-time slot numbers (A/B reference)
     (void)one_tile;
     int ks0 = 0, ks1 = 1, ks2 = 2;
+    if constexpr (PLACED) {
+        bf16x8 PA[4], PB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) PB[i][j] = (__bf16)0.f;
+        kpre_l = kfrag(0, 1, 0, 1); kpre_h = kfrag(0, 1, 0, 0);
+#if VH_ATTN_PRIO
+        if (wv >= 4) __builtin_amdgcn_s_setprio(1);         // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+#endif
+        // ring position of tile t = t mod 3 for K and V alike: K of tiles t, t+1, t+2 and V of tiles t, t+1, t-1 sit in slots (p, p+1, p+2) mod 3
+        auto tile3 = [&](auto pc, int tile) __attribute__((always_inline)) {
+            constexpr int P0 = decltype(pc)::value, P1 = (P0 + 1) % 3, P2 = (P0 + 2) % 3;
+            const int k0 = tile * KT;
+            const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
+            if (more2) loadK();
+            if (more1) loadV();
+            step3(P2, 1, P0, 1, k0, is_tail(tile), P1, 0, PB, PA);                    // P.V of (tile-1, keys 32..63)
+            step3(P0, 0, P1, 0, k0 + KT, is_tail(tile + 1), P1, 1, PA, PB);           // P.V of (tile, keys 0..31); the next tile's first step reads K slot P1
+            if (more2) storeK(P2, k0 + 2 * KT, is_tail(tile + 2));
+            if (more1) storeV(P1, k0 + KT, is_tail(tile + 1));
+            __syncthreads();
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        int tile = 0;
+        for (; tile + 3 <= ntiles; tile += 3) {             // three tiles per trip, straight-line (a per-tile dispatch on the phase made hipcc shuffle the live state between the three bodies)
+            tile3(I0{}, tile); tile3(I1{}, tile + 1); tile3(I2{}, tile + 2);
+        }
+        if (tile < ntiles) tile3(I0{}, tile);
+        if (tile + 1 < ntiles) tile3(I1{}, tile + 1);
+        const int vs2 = (ntiles + 2) % 3;                   // slot of the last tile ((ntiles - 1) mod 3)
+        drain3(vs2, 1, PB);
+        lsum += lsum0 + lsum1;
+        lsum += __shfl_xor(lsum0 + lsum1, 32);
+    } else
     for (int tile = 0; tile < ntiles; ++tile) {
         const int k0 = tile * KT;
         const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
