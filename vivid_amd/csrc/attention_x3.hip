@@ -574,9 +574,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 #define VH_MFMA_O(a_, b_, c_) c_ = VH_MFMA(a_, b_, c_)
     float lsum0 = 0.f, lsum1 = 0.f;
     // pin / pout: {hi keys 0-15, lo keys 0-15, hi keys 16-31, lo keys 16-31} of the previous / this sub-tile's P
+    // skc / svc: integral constants, the K / V ring slot this step's regions also fill from the staging registers (-1: none; the
+    // generic tile body stores after its steps, with the ragged-tail masks)
     auto step3 = [&](int vslot, int vks, int nslot, int nks, int nk0, bool ntail, int pslot, int pks,
-                     const bf16x8 (&pin)[4], bf16x8 (&pout)[4]) __attribute__((always_inline)) {
+                     const bf16x8 (&pin)[4], bf16x8 (&pout)[4], auto skc, auto svc) __attribute__((always_inline)) {
       if constexpr (D == 64) {
+        constexpr int SK = decltype(skc)::value, SV = decltype(svc)::value;
+        static_assert(KPT == 2 && VPT == 2, "step3 places two K and two V staging stores");
         float e[16];
         unsigned hw[8], lw[8];
         float t0[8], t1[8];
@@ -616,11 +620,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         // 4
         const bf16x8 k2l = kfrag(nslot, nks, 2, 1), k2h = kfrag(nslot, nks, 2, 0);
         VH_MFMA_O(v00l, pin[0], oacc[0]); EA(1); VH_SB();
+        if constexpr (SK >= 0) sK[SK][ksl[0]] = rk[0];
         snext = VH_MFMA(k1l, qh[1], snext); EB(1); VH_SB();
         const bf16x8 v01l = vfrag(vslot, vks, 0, 1, 1), v01h = vfrag(vslot, vks, 0, 1, 0);
         VH_MFMA_O(v00h, pin[1], oacc[0]); EC(1); VH_SB();
         // 7
         snext = VH_MFMA(k1h, ql[1], snext); EA(2); VH_SB();
+        if constexpr (SK >= 0) sK[SK][ksl[1]] = rk[1];
         VH_MFMA_O(v00h, pin[0], oacc[0]); EB(2); VH_SB();
         const bf16x8 k3l = kfrag(nslot, nks, 3, 1), k3h = kfrag(nslot, nks, 3, 0);
         snext = VH_MFMA(k1h, qh[1], snext); EC(2); VH_SB();
@@ -628,6 +634,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         VH_MFMA_O(v01l, pin[0], oacc[1]); EA(3); VH_SB();
         const bf16x8 v10l = vfrag(vslot, vks, 1, 0, 1), v10h = vfrag(vslot, vks, 1, 0, 0);
         snext = VH_MFMA(k2l, qh[2], snext); EB(3); VH_SB();
+        if constexpr (SV >= 0) sV[SV][vsl[0]] = rv[0];
         VH_MFMA_O(v01h, pin[1], oacc[1]); EC(3); VH_SB();
         // 13
         snext = VH_MFMA(k2h, ql[2], snext); EA(4); VH_SB();
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         const bf16x8 v11l = vfrag(vslot, vks, 1, 1, 1), v11h = vfrag(vslot, vks, 1, 1, 0);
         snext = VH_MFMA(k2h, qh[2], snext); EC(4); VH_SB();
         // 16
+        if constexpr (SV >= 0) sV[SV][vsl[1]] = rv[1];
         VH_MFMA_O(v10l, pin[2], oacc[0]); EA(5); VH_SB();
         snext = VH_MFMA(k3l, qh[3], snext); EB(5); VH_SB();
         VH_MFMA_O(v10h, pin[3], oacc[0]); EC(5); VH_SB();
@@ -730,25 +738,41 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         if (wv >= 4) __builtin_amdgcn_s_setprio(1);         // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
 #endif
         // ring position of tile t = t mod 3 for K and V alike: K of tiles t, t+1, t+2 and V of tiles t, t+1, t-1 sit in slots (p, p+1, p+2) mod 3
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using IN = std::integral_constant<int, -1>;
         auto tile3 = [&](auto pc, int tile) __attribute__((always_inline)) {
             constexpr int P0 = decltype(pc)::value, P1 = (P0 + 1) % 3, P2 = (P0 + 2) % 3;
             const int k0 = tile * KT;
             const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
             if (more2) loadK();
             if (more1) loadV();
-            step3(P2, 1, P0, 1, k0, is_tail(tile), P1, 0, PB, PA);                    // P.V of (tile-1, keys 32..63)
-            step3(P0, 0, P1, 0, k0 + KT, is_tail(tile + 1), P1, 1, PA, PB);           // P.V of (tile, keys 0..31); the next tile's first step reads K slot P1
+            step3(P2, 1, P0, 1, k0, is_tail(tile), P1, 0, PB, PA, IN{}, IN{});        // P.V of (tile-1, keys 32..63)
+            step3(P0, 0, P1, 0, k0 + KT, is_tail(tile + 1), P1, 1, PA, PB, IN{}, IN{}); // P.V of (tile, keys 0..31); the next tile's first step reads K slot P1
             if (more2) storeK(P2, k0 + 2 * KT, is_tail(tile + 2));
             if (more1) storeV(P1, k0 + KT, is_tail(tile + 1));
             __syncthreads();
         };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        // a tile whose two successors exist and hold no ragged tail: no branches, the staging stores ride in the second step's regions
+        auto tileM = [&](auto pc, int tile) __attribute__((always_inline)) {
+            constexpr int P0 = decltype(pc)::value, P1 = (P0 + 1) % 3, P2 = (P0 + 2) % 3;
+            const int k0 = tile * KT;
+            loadK(); loadV();
+            // (the tail tests are never true here; left in as run-time branches they end the basic block after each step - in one block
+            //  of two or six steps instruction selection already emits the first step's VALU in clumps, before any sched_barrier applies)
+            step3(P2, 1, P0, 1, k0, is_tail(tile), P1, 0, PB, PA, IN{}, IN{});
+            step3(P0, 0, P1, 0, k0 + KT, is_tail(tile + 1), P1, 1, PA, PB, std::integral_constant<int, P2>{}, std::integral_constant<int, P1>{});
+            __syncthreads();
+        };
+        const int nmain = ntiles - (ragged ? 3 : 2);
         int tile = 0;
-        for (; tile + 3 <= ntiles; tile += 3) {             // three tiles per trip, straight-line (a per-tile dispatch on the phase made hipcc shuffle the live state between the three bodies)
-            tile3(I0{}, tile); tile3(I1{}, tile + 1); tile3(I2{}, tile + 2);
+        for (; tile + 3 <= nmain; tile += 3) {              // three tiles per trip, straight-line (a per-tile dispatch on the ring phase made hipcc shuffle the live state between the bodies)
+            tileM(I0{}, tile); tileM(I1{}, tile + 1); tileM(I2{}, tile + 2);
         }
-        if (tile < ntiles) tile3(I0{}, tile);
+        if (tile < ntiles) tile3(I0{}, tile);               // the last <= 5 tiles, generic
         if (tile + 1 < ntiles) tile3(I1{}, tile + 1);
+        if (tile + 2 < ntiles) tile3(I2{}, tile + 2);
+        if (tile + 3 < ntiles) tile3(I0{}, tile + 3);
+        if (tile + 4 < ntiles) tile3(I1{}, tile + 4);
         const int vs2 = (ntiles + 2) % 3;                   // slot of the last tile ((ntiles - 1) mod 3)
         drain3(vs2, 1, PB);
         lsum += lsum0 + lsum1;
