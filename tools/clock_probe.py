@@ -19,7 +19,7 @@ from vivid_amd import _lib as L  # noqa: E402
 
 kind = sys.argv[1]
 args = [int(x) for x in sys.argv[2:]]
-L.LIB_PATH = os.path.join(ROOT, "vivid_amd", "libvivid_hip_clkc.so" if kind == "conv" else "libvivid_hip_clka.so")
+L.LIB_PATH = os.path.join(ROOT, "vivid_amd", os.environ.get("CLOCK_LIB", "libvivid_hip_clkc.so" if kind == "conv" else "libvivid_hip_clka.so"))
 ctx = L.Context(torch.cuda.current_stream().cuda_stream)
 dbg = torch.zeros(12 << 14, dtype=torch.int64, device="cuda")
 L.set_knob("dbg_lo", dbg.data_ptr() & 0xFFFFFFFF if (dbg.data_ptr() & 0xFFFFFFFF) < 2 ** 31 else (dbg.data_ptr() & 0xFFFFFFFF) - 2 ** 32)

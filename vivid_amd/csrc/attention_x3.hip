@@ -78,6 +78,16 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
     }
 }
 
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma_abl16(bf16x8 a, bf16x8 b, f32x16 c) {
+    f32x4v q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]};
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { c[i] = q0[i]; c[4 + i] = q1[i]; }
+    return c;
+}
+
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_bf16x3(const AttnXK a) {
     constexpr int NT = NW * 64;
@@ -570,7 +580,11 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         return *(lds_frag_ptr)(size_t)(voff[vks][s2][lohi] + (unsigned)(slot * (V_UNITS * 16) + dt * 8192));
     };
 #define VH_SB() __builtin_amdgcn_sched_barrier(0)
+#if defined(VH_ATTN_ABLATE) && (VH_ATTN_ABLATE & 4)     // timing ablation build (WRONG results): every 32x32x16 MFMA as two 16x16x32 MFMAs (same FLOPs)
+#define VH_MFMA(a_, b_, c_) mfma_abl16(a_, b_, c_)
+#else
 #define VH_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_, b_, c_, 0, 0, 0)
+#endif
 #define VH_MFMA_O(a_, b_, c_) c_ = VH_MFMA(a_, b_, c_)
     float lsum0 = 0.f, lsum1 = 0.f;
     // pin / pout: {hi keys 0-15, lo keys 0-15, hi keys 16-31, lo keys 16-31} of the previous / this sub-tile's P
@@ -715,6 +729,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         if (more1) storeV(VS1, k0 + KT, is_tail(tile + 1));
         __syncthreads();
     };
+#ifdef VH_CLOCK
+    unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
 #if VH_ATTN_STATIC_SLOTS
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     int phase = 0;
@@ -761,7 +779,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
             //  of two or six steps instruction selection already emits the first step's VALU in clumps, before any sched_barrier applies)
             step3(P2, 1, P0, 1, k0, is_tail(tile), P1, 0, PB, PA, IN{}, IN{});
             step3(P0, 0, P1, 0, k0 + KT, is_tail(tile + 1), P1, 1, PA, PB, std::integral_constant<int, P2>{}, std::integral_constant<int, P1>{});
+#if !(defined(VH_ATTN_ABLATE) && (VH_ATTN_ABLATE & 2))   // timing ablation build (WRONG results): no tile barrier
             __syncthreads();
+#endif
         };
         const int nmain = ntiles - (ragged ? 3 : 2);
         int tile = 0;
