@@ -48,6 +48,7 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
 
 /* Process-wide diagnostic knobs, read when an op is issued or recorded; none changes results.  "attn_xcd": 1 (default) places
  * every (batch, head) of the bf16x3 attention on one XCD, 0 keeps the plain workgroup order (A/B timing in one process);
+ * "attn_m16": 1 (default) runs 64-channel bounded-logit attention on the 16x16x32 MFMA kernel, 0 on the 32x32x16 one;
  * "dbg_lo" / "dbg_hi": the two halves of a device pointer that receives the clock stamps of the diagnostic builds
  * (-DVH_CLOCK, tools/clock_probe.py) - the product build never writes to it.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);

@@ -861,6 +861,398 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_fwd_x3_m16: 64-channel heads, bounded logits (no running maximum), KL > 64 - the attention of the benchmark's networks.
+// The three-stage placed step of attn_fwd_bf16x3_pipe (step i: QK^T of sub-tile i+1, exp2 / row sum / hi-lo split of sub-tile i, P.V of
+// sub-tile i-1; compile-time ring slots, staging stores inside the step) on v_mfma_f32_16x16x32_bf16: same FLOPs and matrix-pipe cycles
+// per step as the 32x32x16 form (48 x 16 instead of 24 x 32 cycles), but the chip holds a higher clock under it - measured here with
+// the in-kernel stamps, same device, 2.10 GHz against 1.62 GHz at +2 % cycles (MI355X_MICROARCH.md, DVFS give-back item 7; the
+// convolutions use the same shape for the same reason).
+//   S^T tile (mk, nq) = 16 keys x 16 queries; a wave holds 2 x 2 of them per 32-key sub-tile (32 queries per wave as before).
+//   A = K rows: lane (i = l&15, g = l>>4) supplies key (i&7) + 8 mk + 16 (i>>3) of the sub-tile, channels 32 kstep + 8 g .. +7: with
+//   that row order the accumulators of lane group g (rows 4g..4g+3 of both tiles) are exactly the eight keys of one 16-byte unit of
+//   the V^T image (positions 8h..8h+7 of 16-key block blk, g = 2 blk + h), so P never leaves registers here either: the two tiles'
+//   accumulators, split to bf16 hi/lo pairs, are the B operand (32 keys x 16 queries) of O^T += V^T P^T, and the global V^T format is
+//   the one the 32x32x16 kernels read.  K slots in LDS carry one more swizzle term (bit 3 ^= key bit 4) so that those 16 rows fall in
+//   16 different bank groups.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
+    constexpr int D = 64, NT = 512, KU = D / 4;
+    constexpr int K_UNITS = KU * KT, V_UNITS = D * 2 * (KT / 8);
+    constexpr int KPT = K_UNITS / NT, VPT = V_UNITS / NT;
+    static_assert(KPT == 2 && VPT == 2, "two K and two V staging units per thread and tile");
+    __shared__ uint4 sK[3][K_UNITS];
+    __shared__ uint4 sV[3][V_UNITS];
+
+    const int t = threadIdx.x;
+    const int wv = t >> 6, l = t & 63, li = l & 15, g = l >> 4;
+    int bx, bh;
+    attn_coords(a, bx, bh);
+    const int b = bh / a.heads, hd = bh - b * a.heads;
+    const int qrow0 = bx * 256 + wv * 32 + li;               // this lane's query in block nq: qrow0 + 16 nq
+
+    // Q fragments (B operand): query li of block nq, channels 32 kstep + 8 g .. +7
+    bf16x8 qh[2][2], ql[2][2];
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+        const int qrow = qrow0 + 16 * nq;
+        const float* Qb = a.q + ((size_t)bh * a.s + (qrow < a.s ? qrow : 0)) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float v[8];
+            const float4 p0 = *reinterpret_cast<const float4*>(Qb + ks * 32);
+            const float4 p1 = *reinterpret_cast<const float4*>(Qb + ks * 32 + 4);
+            v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
+            if (qrow >= a.s) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            split8(v, qh[nq][ks], ql[nq][ks]);
+        }
+    }
+    f32x4 o[4][2];                                           // O^T: channels 16 md + 4 g + r of query (nq, li)
+#pragma unroll
+    for (int md = 0; md < 4; ++md)
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[md][nq][r] = 0.f;
+
+    // staging: global -> registers -> LDS, as in attn_fwd_bf16x3_pipe (K rows get the extra swizzle term)
+    const uint4* kp[KPT];
+    const uint4* vp[VPT];
+    int ksl[KPT], vsl[VPT], kkey[KPT], vku[VPT];
+    {
+        const uint4* Kb = a.k + (size_t)bh * a.klp * KU;
+        const uint4* Vb = a.vt + (size_t)bh * D * 2 * (a.klp / 8);
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const int idx = t + i * NT;
+            const int key = idx / KU, u = idx - key * KU;
+            kp[i] = Kb + (size_t)key * KU + u;
+            ksl[i] = u * KT + (key ^ (u & 7) ^ (((key >> 4) & 1) << 3));
+            kkey[i] = key;
+        }
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            const int idx = t + i * NT;
+            const int row = idx >> 3, ku = idx & 7;
+            const int d = row >> 1, hl = row & 1;
+            vp[i] = Vb + (size_t)row * (a.klp / 8) + ku;
+            vsl[i] = d * 16 + ((hl * 8 + ku) ^ (d & 15));
+            vku[i] = ku;
+        }
+    }
+    uint4 rk[KPT], rv[VPT];
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto loadK = [&]() {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) { rk[i] = *kp[i]; kp[i] += KT * KU; }
+    };
+    auto loadV = [&]() {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) { rv[i] = *vp[i]; vp[i] += KT / 8; }
+    };
+    auto storeK = [&](int slot, int k0, bool tail) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            uint4 v = rk[i];
+            if (tail && k0 + kkey[i] >= a.kl) v = zero4;
+            sK[slot][ksl[i]] = v;
+        }
+    };
+    auto storeV = [&](int slot, int k0, bool tail) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) {
+            uint4 v = rv[i];
+            if (tail && k0 + (vku[i] >> 1) * 16 + 16 > a.kl) {
+                unsigned short* e = reinterpret_cast<unsigned short*>(&v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int pos = vku[i] * 8 + j;
+                    const int key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);
+                    if (k0 + key >= a.kl) e[j] = 0;
+                }
+            }
+            sV[slot][vsl[i]] = v;
+        }
+    };
+
+    const int ntiles = (a.kl + KT - 1) / KT;
+    const bool ragged = (a.kl % KT) != 0;
+    auto is_tail = [&](int tile) { return ragged && tile == ntiles - 1; };
+
+    // fragment addresses: per-lane LDS byte addresses in slot 0 (K: first 32 keys of the tile); slot, sub-tile and 16-channel block
+    // are compile-time offsets of the ds_read
+    unsigned koff[2][2][2], voff[2][2];                      // [mk][kstep][hi, lo]; [keys 0-31 / 32-63][hi, lo]
+    {
+        const unsigned kbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sK[0][0];
+        const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sV[0][0];
+#pragma unroll
+        for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int lohi = 0; lohi < 2; ++lohi) {
+                    const int key = (li & 7) + 8 * mk + 16 * (li >> 3);
+                    const int u = (ks * 4 + g) * 2 + lohi;
+                    koff[mk][ks][lohi] = kbase + (unsigned)(u * KT + (key ^ (u & 7) ^ ((li >> 3) << 3))) * 16u;
+                    asm("" : "+v"(koff[mk][ks][lohi]));
+                    koff[mk][ks][lohi] &= 0x3ffffu;
+                }
+#pragma unroll
+        for (int vks = 0; vks < 2; ++vks)
+#pragma unroll
+            for (int lohi = 0; lohi < 2; ++lohi) {
+                voff[vks][lohi] = vbase + (unsigned)(li * 16 + ((lohi * 8 + vks * 4 + g) ^ li)) * 16u;
+                asm("" : "+v"(voff[vks][lohi]));
+                voff[vks][lohi] &= 0x3ffffu;
+            }
+    }
+    typedef const __attribute__((address_space(3))) bf16x8* lds_frag_ptr;
+    auto kfrag = [&](int slot, int ks32, int mk, int kstep, int lohi) __attribute__((always_inline)) -> bf16x8 {
+        return *(lds_frag_ptr)(size_t)(koff[mk][kstep][lohi] + (unsigned)(slot * (K_UNITS * 16) + ks32 * 512));
+    };
+    auto vfrag = [&](int slot, int vks, int md, int lohi) __attribute__((always_inline)) -> bf16x8 {
+        return *(lds_frag_ptr)(size_t)(voff[vks][lohi] + (unsigned)(slot * (V_UNITS * 16) + md * 4096));
+    };
+#define VH_MFMA16(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c_, 0, 0, 0)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // keys past the end of a ragged last tile get -inf logits: element r of tile mk in lane group g is key 4(g&1) + r + 16(g>>1) + 8 mk
+    auto mask_tail = [&](f32x4 (&s)[2][2], int k0, int ks32) {
+        const int kb = k0 + ks32 * 32 + 4 * (g & 1) + 16 * (g >> 1);
+#pragma unroll
+        for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kb + 8 * mk + r >= a.kl) { s[mk][0][r] = -INFINITY; s[mk][1][r] = -INFINITY; }
+    };
+
+    f32x4 scur[2][2], snext[2][2];
+    float lsum[2] = {0.f, 0.f};                              // per lane: its 8 keys per step of query (nq, li); the 4 lane groups are added after the loop
+    bf16x8 kpre[2], vpre[2];                                 // first K / V fragment pair of the next step, read one step ahead ([hi, lo])
+
+    // one step = 24 regions of (one QK^T MFMA, one P.V MFMA, one third of a logit pair's softmax); pin / pout: [nq][hi, lo]
+    auto step = [&](auto vslc, auto vksc, auto nslc, auto nksc, int nk0, bool ntail, auto pslc, auto pksc, auto pvslc, auto pvksc,
+                    const bf16x8 (&pin)[2][2], bf16x8 (&pout)[2][2], auto skc, auto svc) __attribute__((always_inline)) {
+        constexpr int VSL = decltype(vslc)::value, VKS = decltype(vksc)::value, NSL = decltype(nslc)::value, NKS = decltype(nksc)::value;
+        constexpr int PSL = decltype(pslc)::value, PKS = decltype(pksc)::value, PVSL = decltype(pvslc)::value, PVKS = decltype(pvksc)::value;
+        constexpr int SK = decltype(skc)::value, SV = decltype(svc)::value;
+        float e[16];
+        unsigned hw[8], lw[8];
+        float t0[8], t1[8];
+        bf16x8 kf[4][2], vf[4][2];                           // [block of 6 MFMAs][hi, lo]
+        kf[0][0] = kpre[0]; kf[0][1] = kpre[1]; vf[0][0] = vpre[0]; vf[0][1] = vpre[1];
+        auto cvt2 = [](float x, float y) __attribute__((always_inline)) -> unsigned {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            bf16x2 v; v[0] = (__bf16)x; v[1] = (__bf16)y;
+            unsigned r = __builtin_bit_cast(unsigned, v);
+            asm("" : "+v"(r));                               // opaque: hipcc otherwise converts x a second time on its own for x - hi(x)
+            return r;
+        };
+        auto frag4 = [](unsigned a0, unsigned a1, unsigned a2, unsigned a3) __attribute__((always_inline)) -> bf16x8 {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v = {a0, a1, a2, a3};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        static_for<0, 24>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int R = decltype(rc)::value;
+            constexpr int blk = R / 6, j = R % 6, nq = j & 1;
+            // fragment reads, issued five regions ahead of their first MFMA
+            if constexpr (j == 1 && blk < 3) {
+                constexpr int nb = blk + 1;
+                kf[nb][0] = kfrag(NSL, NKS, nb >> 1, nb & 1, 0); kf[nb][1] = kfrag(NSL, NKS, nb >> 1, nb & 1, 1);
+                vf[nb][0] = vfrag(VSL, VKS, nb, 0); vf[nb][1] = vfrag(VSL, VKS, nb, 1);
+            }
+            if constexpr (R == 19) {
+                kpre[0] = kfrag(PSL, PKS, 0, 0, 0); kpre[1] = kfrag(PSL, PKS, 0, 0, 1);
+                vpre[0] = vfrag(PVSL, PVKS, 0, 0); vpre[1] = vfrag(PVSL, PVKS, 0, 1);
+            }
+            if constexpr (SK >= 0 && R == 4) sK[SK][ksl[0]] = rk[0];
+            if constexpr (SK >= 0 && R == 8) sK[SK][ksl[1]] = rk[1];
+            if constexpr (SV >= 0 && R == 12) sV[SV][vsl[0]] = rv[0];
+            if constexpr (SV >= 0 && R == 16) sV[SV][vsl[1]] = rv[1];
+            // QK^T: block = (mk, kstep); j: lo.hi, lo.hi | hi.lo, hi.lo | hi.hi, hi.hi for query blocks 0, 1
+            {
+                constexpr int mk = blk >> 1, kstep = blk & 1;
+                const bf16x8 afrag = kf[blk][j < 2 ? 1 : 0];
+                const bf16x8 bfrag = (j == 2 || j == 3) ? ql[nq][kstep] : qh[nq][kstep];
+                snext[mk][nq] = VH_MFMA16(afrag, bfrag, (kstep == 0 && j < 2) ? zero : snext[mk][nq]);
+            }
+            // P.V: block = 16 channels md
+            {
+                const bf16x8 afrag = vf[blk][j < 2 ? 1 : 0];
+                const bf16x8 bfrag = (j == 2 || j == 3) ? pin[nq][1] : pin[nq][0];
+                o[blk][nq] = VH_MFMA16(afrag, bfrag, o[blk][nq]);
+            }
+            // softmax of pair p = R / 3: word w of query block q2's P fragment = elements 2(w&1), 2(w&1)+1 of tile mk = w >> 1
+            {
+                constexpr int p = R / 3, piece = R % 3, q2 = p >> 2, w = p & 3, mk = w >> 1, r0 = 2 * (w & 1);
+                if constexpr (piece == 0) {
+                    e[2 * p] = __builtin_amdgcn_exp2f(scur[mk][q2][r0]); e[2 * p + 1] = __builtin_amdgcn_exp2f(scur[mk][q2][r0 + 1]);
+                } else if constexpr (piece == 1) {
+                    hw[p] = cvt2(e[2 * p], e[2 * p + 1]);
+                    lsum[q2] += e[2 * p]; lsum[q2] += e[2 * p + 1];
+                    t0[p] = __uint_as_float(hw[p] << 16); t1[p] = __uint_as_float(hw[p] & 0xffff0000u);
+                } else {
+                    lw[p] = cvt2(e[2 * p] - t0[p], e[2 * p + 1] - t1[p]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // (row sums are needed only after the loop: one volatile use per step keeps their adds in this block, where the sched_barriers hold them)
+        asm volatile("" : "+v"(lsum[0]), "+v"(lsum[1]));
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+            pout[q2][0] = frag4(hw[4 * q2], hw[4 * q2 + 1], hw[4 * q2 + 2], hw[4 * q2 + 3]);
+            pout[q2][1] = frag4(lw[4 * q2], lw[4 * q2 + 1], lw[4 * q2 + 2], lw[4 * q2 + 3]);
+        }
+        if (ntail) mask_tail(snext, nk0, NKS);
+#pragma unroll
+        for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) scur[mk][q2] = snext[mk][q2];
+    };
+
+    // prologue: K[0], V[0], K[1] in LDS; logits of sub-tile 0; V slot 2 ("tile -1", multiplied by P = 0 in the first step) zeroed
+    loadK(); loadV();
+    storeK(0, 0, is_tail(0)); storeV(0, 0, is_tail(0));
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) sV[2][vsl[i]] = zero4;
+    if (ntiles > 1) { loadK(); storeK(1, KT, is_tail(1)); }
+    __syncthreads();
+#pragma unroll
+    for (int mk = 0; mk < 2; ++mk)
+#pragma unroll
+        for (int nq = 0; nq < 2; ++nq) {
+            f32x4 acc = zero;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kh = kfrag(0, 0, mk, ks, 0), kl_ = kfrag(0, 0, mk, ks, 1);
+                acc = VH_MFMA16(kl_, qh[nq][ks], acc);
+                acc = VH_MFMA16(kh, ql[nq][ks], acc);
+                acc = VH_MFMA16(kh, qh[nq][ks], acc);
+            }
+            scur[mk][nq] = acc;
+        }
+    if (is_tail(0)) mask_tail(scur, 0, 0);
+
+    bf16x8 PA[2][2], PB[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) PB[i][h2][j] = (__bf16)0.f;
+    kpre[0] = kfrag(0, 1, 0, 0, 0); kpre[1] = kfrag(0, 1, 0, 0, 1);          // the first step computes the logits of (tile 0, keys 32..63)
+    vpre[0] = vfrag(2, 1, 0, 0); vpre[1] = vfrag(2, 1, 0, 1);                //   and multiplies P = 0 with "tile -1"
+#ifdef VH_CLOCK
+    unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    // ring position of tile t = t mod 3 for K and V alike: K of tiles t, t+1, t+2 and V of tiles t, t+1, t-1 sit in slots (p, p+1, p+2) mod 3
+    using IN = std::integral_constant<int, -1>;
+    auto tile_body = [&](auto pc, auto mainc, int tile) __attribute__((always_inline)) {
+        constexpr int P0 = decltype(pc)::value, P1 = (P0 + 1) % 3, P2 = (P0 + 2) % 3;
+        constexpr bool MAIN = decltype(mainc)::value;        // two successors, no ragged tail among them: no conditions, staging stores inside the second step
+        using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+        using S0 = std::integral_constant<int, P0>; using S1 = std::integral_constant<int, P1>; using S2 = std::integral_constant<int, P2>;
+        const int k0 = tile * KT;
+        const bool more1 = MAIN || tile + 1 < ntiles, more2 = MAIN || tile + 2 < ntiles;
+        if (more2) loadK();
+        if (more1) loadV();
+        // step 1: logits of (tile, keys 32..63) from K slot P0; P.V of (tile-1, keys 32..63) from V slot P2; next step: K (tile+1, 0..31) = slot P1, V (tile, 0..31) = slot P0
+        step(S2{}, C1{}, S0{}, C1{}, k0, is_tail(tile), S1{}, C0{}, S0{}, C0{}, PB, PA, IN{}, IN{});
+        // step 2: logits of (tile+1, keys 0..31) from K slot P1; P.V of (tile, keys 0..31); next step: K (tile+1, 32..63) = slot P1, V (tile, 32..63) = slot P0
+        if constexpr (MAIN) step(S0{}, C0{}, S1{}, C0{}, k0 + KT, is_tail(tile + 1), S1{}, C1{}, S0{}, C1{}, PA, PB, S2{}, S1{});
+        else {
+            step(S0{}, C0{}, S1{}, C0{}, k0 + KT, is_tail(tile + 1), S1{}, C1{}, S0{}, C1{}, PA, PB, IN{}, IN{});
+            if (more2) storeK(P2, k0 + 2 * KT, is_tail(tile + 2));
+            if (more1) storeV(P1, k0 + KT, is_tail(tile + 1));
+        }
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+    const int nmain = ntiles - (ragged ? 3 : 2);
+    int tile = 0;
+    for (; tile + 3 <= nmain; tile += 3) {                  // three tiles per trip, straight-line
+        tile_body(I0{}, std::true_type{}, tile); tile_body(I1{}, std::true_type{}, tile + 1); tile_body(I2{}, std::true_type{}, tile + 2);
+    }
+    if (tile < ntiles) tile_body(I0{}, std::false_type{}, tile);             // the last <= 5 tiles, generic
+    if (tile + 1 < ntiles) tile_body(I1{}, std::false_type{}, tile + 1);
+    if (tile + 2 < ntiles) tile_body(I2{}, std::false_type{}, tile + 2);
+    if (tile + 3 < ntiles) tile_body(I0{}, std::false_type{}, tile + 3);
+    if (tile + 4 < ntiles) tile_body(I1{}, std::false_type{}, tile + 4);
+    // P.V of the last sub-tile (its P is still in registers): V slot (ntiles - 1) mod 3, keys 32..63
+    {
+        const int vs = (ntiles + 2) % 3;
+#pragma unroll
+        for (int md = 0; md < 4; ++md) {
+            const bf16x8 vh = *(lds_frag_ptr)(size_t)(voff[1][0] + (unsigned)(vs * (V_UNITS * 16) + md * 4096));
+            const bf16x8 vl = *(lds_frag_ptr)(size_t)(voff[1][1] + (unsigned)(vs * (V_UNITS * 16) + md * 4096));
+#pragma unroll
+            for (int nq = 0; nq < 2; ++nq) {
+                o[md][nq] = VH_MFMA16(vl, PB[nq][0], o[md][nq]);
+                o[md][nq] = VH_MFMA16(vh, PB[nq][1], o[md][nq]);
+                o[md][nq] = VH_MFMA16(vh, PB[nq][0], o[md][nq]);
+            }
+        }
+    }
+#ifdef VH_CLOCK
+    {
+        const unsigned long long ck_m1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (a.dbg && t == 0) { a.dbg[(size_t)blockIdx.x * 2] = ck_m1 - ck_m0; a.dbg[(size_t)blockIdx.x * 2 + 1] = ck_r1 - ck_r0; }
+    }
+#endif
+
+    // output: lane (li, g) holds channels 16 md + 4 g .. +3 of queries qrow0 and qrow0 + 16
+#pragma unroll
+    for (int nq = 0; nq < 2; ++nq) {
+        float ls = lsum[nq];
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        const float inv = 1.0f / (ls + a.n_zero);
+        const int qrow = qrow0 + 16 * nq;
+        if (qrow >= a.s) continue;
+        if (a.out_s8) {
+            // S8: per 8 channels [hi x8 | lo x8] bf16; this lane owns half a chunk (4 channels): two 8-byte stores
+            unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + (((size_t)b * a.s + qrow) * a.c + hd * D) * 2;
+#pragma unroll
+            for (int md = 0; md < 4; ++md) {
+                unsigned h[4], lo4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = o[md][nq][r] * inv;
+                    h[r] = bf16_rn_bits(v);
+                    lo4[r] = bf16_rn_bits(v - __uint_as_float(h[r] << 16));
+                }
+                unsigned short* q8 = op + (md * 16 + 8 * (g >> 1)) * 2 + 4 * (g & 1);
+                *reinterpret_cast<uint2*>(q8) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(q8 + 8) = make_uint2(lo4[0] | (lo4[1] << 16), lo4[2] | (lo4[3] << 16));
+            }
+        } else {
+            float* op = a.out + ((size_t)b * a.s + qrow) * a.c + hd * D;
+#pragma unroll
+            for (int md = 0; md < 4; ++md) {
+                float4 w;
+                w.x = o[md][nq][0] * inv; w.y = o[md][nq][1] * inv; w.z = o[md][nq][2] * inv; w.w = o[md][nq][3] * inv;
+                *reinterpret_cast<float4*>(op + md * 16 + 4 * g) = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // q/k/v split + head norm writing the operand formats above (view/normalize/unbind of
 // training/models.py:192-194, :279-293; sequence concat :296-297 via koff).
 // One workgroup = one (row, head) x 64 consecutive pixels.
@@ -1017,8 +1409,10 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     const double bhd = (double)a.b * a.heads;
     const double flops = 4.0 * bhd * a.s * a.kl * a.d;
     const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);
-    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, nomax, grid](hipStream_t s) -> int {
-        if (pipe && d == 64 && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64, true>), grid, dim3(512), 0, s, k);
+    const bool m16 = vh_knob(VH_KNOB_ATTN_M16) != 0;        // knob "attn_m16" = 0: the 32x32x16 placed kernel (A/B)
+    return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, nomax, m16, grid](hipStream_t s) -> int {
+        if (pipe && d == 64 && nomax && m16) hipLaunchKernelGGL(attn_fwd_x3_m16, grid, dim3(512), 0, s, k);
+        else if (pipe && d == 64 && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64, true>), grid, dim3(512), 0, s, k);
         else if (pipe && d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
         else if (pipe && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32, true>), grid, dim3(512), 0, s, k);
         else if (pipe) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32>), grid, dim3(512), 0, s, k);

@@ -40,7 +40,7 @@ struct vh_ctx {
 int vh_run_op(vh_ctx* ctx, const vh_op& op);
 
 // process-wide scheduling knobs (vh_set_knob)
-enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_NUM_KNOBS = 3 };
+enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATTN_M16 = 3, VH_NUM_KNOBS = 4 };
 int vh_knob(int id);
 // device buffer for the stamps of diagnostic builds (-DVH_CLOCK), set through the knobs "dbg_lo"/"dbg_hi"; null otherwise
 inline unsigned long long* vh_debug_ptr() {
