@@ -440,6 +440,45 @@ def test_attention_headline_slice_vs_sdpa(ctx, b, heads, s, kl, d, nz):
     test_qkv_split_and_attention(ctx, 2, b, heads, s, kl, d, nz)
 
 
+@pytest.mark.parametrize("kl", [65, 128, 129, 191, 192, 256, 320, 321, 384, 449, 512, 577, 640, 705])
+@pytest.mark.parametrize("m16", [1, 0])
+def test_attention_bounded_logits_tile_counts_and_s8_output(ctx, kl, m16):
+    """The 64-channel bounded-logit kernels (attn_fwd_x3_m16; knob attn_m16 = 0: the 32x32x16 form) walk the key tiles three per trip
+    with the last <= 5 handled separately, ragged or not: every tile count from 2 to 12 with and without a key tail, ragged query
+    tail (s = 100), fp32 and S8 (bf16 hi/lo) outputs, against F.scaled_dot_product_attention."""
+    from vivid_amd import _lib as L
+    b, heads, s, d = 1, 2, 100, 64
+    g = torch.Generator().manual_seed(kl)
+    def unit(t):
+        return t / t.square().mean(dim=-1, keepdim=True).sqrt()
+    q, k, v = (unit(torch.randn(b, heads, n, d, generator=g)) for n in (s, kl, kl))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v)
+    klp = (kl + 63) // 64 * 64
+    def split(t):
+        t = torch.nn.functional.pad(t, (0, 0, 0, klp - kl), value=float("nan")).nan_to_num(nan=3.0)    # pads hold finite junk: must not leak
+        hi = t.to(torch.bfloat16)
+        return hi, (t - hi.to(torch.float32)).to(torch.bfloat16)
+    kh, kl_ = split(k)
+    K8 = torch.stack([kh.view(b, heads, klp, d // 8, 8), kl_.view(b, heads, klp, d // 8, 8)], dim=4).contiguous().cuda()
+    vh, vl = split(v)
+    pos = torch.arange(klp)
+    key_at_pos = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1)
+    VT = torch.stack([vh[:, :, key_at_pos].transpose(-1, -2), vl[:, :, key_at_pos].transpose(-1, -2)], dim=3).contiguous().cuda()
+    Qd = (q * (LOG2E / math.sqrt(d))).contiguous().cuda()
+    L.set_knob("attn_m16", m16)
+    try:
+        for s8 in (0, 1):
+            out = torch.full((b * s * heads * d,), float("nan"), device="cuda")
+            ctx.call("vh_attention_x3", L.AttentionArgs(q=Qd.data_ptr(), k=K8.data_ptr(), v=VT.data_ptr(), b=b, heads=heads, s=s, kl=kl, d=d,
+                                                        n_zero_keys=0.0, out=out.data_ptr(), out_s8=s8, logit_bound=LOG2E * math.sqrt(d) * 1.001))
+            torch.cuda.synchronize()
+            got = _s8_decode(out.cpu(), (b, s, heads * d)) if s8 else out.cpu().view(b, s, heads * d)
+            assert torch.isfinite(got).all()
+            assert rel_l2(got.view(b, s, heads, d).permute(0, 2, 1, 3), ref) < 1e-4, (kl, m16, s8)
+    finally:
+        L.set_knob("attn_m16", 1)
+
+
 def _s8_like_decode(buf, which, bh, klp, D):
     """K ([bh][klp][D/8][hi8|lo8]) or V^T ([bh][D][hl][klp]) operand buffer -> hi + lo as fp32."""
     f = (buf.view(torch.int16).to(torch.int32) << 16).view(torch.float32)
