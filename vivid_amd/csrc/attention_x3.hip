@@ -11,6 +11,9 @@
 //   V^T [bh][D][hl][KLp] bf16, key positions permuted inside every group of 16
 //       (pos = key with bits 2 and 3 swapped) so that the 8 keys one lane half needs for a
 //       16-key MFMA step — the S^T accumulator row map — are one contiguous 16-byte unit.
+// Kernels: attn_fwd_x3_m16 (64-channel heads, bounded logits, KL > 64: the benchmark's attention; hand-placed three-stage step on
+// the 16x16x32 MFMA), attn_fwd_bf16x3_pipe (32-channel heads and running-maximum cases; its <64, true> instantiation is the 32x32x16
+// form of the placed step, knob attn_m16 = 0), attn_fwd_bf16x3 (short sequences).
 // One workgroup = NW waves x 32 queries of one (batch, head); K/V stream through LDS in 64-key
 // tiles, double-buffered, one barrier per tile.  S^T = K Q^T puts the query on the lane, P stays
 // in registers (accumulators -> bf16 pairs -> B operand of O^T += V^T P^T), as in attention.hip.
@@ -27,13 +30,7 @@ namespace {
 
 constexpr int KT = 64;
 constexpr float RESCALE_THR = 8.0f;
-#ifndef VH_ATTN_STATIC_SLOTS
-#define VH_ATTN_STATIC_SLOTS 0     // 1: compile-time LDS slot numbers in the pipelined kernel (6-phase loop): 20 % fewer VALU instructions, measured 10 % SLOWER
-#endif
 
-#ifndef VH_ATTN_PRIO
-#define VH_ATTN_PRIO 0
-#endif
 #ifndef VH_ATTN_PLACED
 #define VH_ATTN_PLACED 1           // hand-placed three-stage step for D = 64 without running maximum (0: compiler-scheduled two-stage step, the A/B reference)
 #endif
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
     constexpr int K_UNITS = KU * KT, V_UNITS = D * 2 * (KT / 8);
     __shared__ uint4 sK[3][K_UNITS];
     constexpr bool PLACED = VH_ATTN_PLACED && NOMAX && D == 64;     // the hand-placed three-stage step (below)
-    __shared__ uint4 sV[(VH_ATTN_STATIC_SLOTS || PLACED) ? 3 : 2][V_UNITS];   // (placed: a tile's values are still read one step into the next tile; static-slot build: pattern repeats every 3 tiles)
+    __shared__ uint4 sV[PLACED ? 3 : 2][V_UNITS];           // (placed: a tile's values are still read one step into the next tile)
 
     const int t = threadIdx.x;
     const int wv = t >> 6, l = t & 63, lr = l & 31, hh = l >> 5;
@@ -713,37 +710,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
         for (int r = 0; r < 16; ++r) { scur[r] -= mx; negm[r] = -mx; }
     }
 
-    // One tile with its LDS slots as compile-time constants: K slots of tiles t, t+1, t+2 are (t, t+1, t+2) mod 3 and (V ring of 3) the
-    // V slot t mod 3, so the pattern repeats every 3 tiles and the loop dispatches on t mod 3.  With run-time slot numbers every ds_read address
-    // was rebuilt per step (12 v_lshl_add + 7 v_or of ~100 VALU per 24 MFMAs, in a loop whose limiter is VALU issue).
-    auto one_tile = [&](auto k0c, auto k1c, auto k2c, int tile) __attribute__((always_inline)) {
-        constexpr int KS0 = decltype(k0c)::value, KS1 = decltype(k1c)::value, KS2 = decltype(k2c)::value;
-        constexpr int VS = KS0, VS1 = KS1;                  // V ring of 3: tile t's values in slot t mod 3, like its keys
-        const int k0 = tile * KT;
-        const bool more1 = tile + 1 < ntiles, more2 = tile + 2 < ntiles;
-        if (more2) loadK();
-        if (more1) loadV();
-        step(VS, 0, KS0, 1, k0, is_tail(tile));
-        step(VS, 1, KS1, 0, k0 + KT, is_tail(tile + 1));
-        if (more2) storeK(KS2, k0 + 2 * KT, is_tail(tile + 2));
-        if (more1) storeV(VS1, k0 + KT, is_tail(tile + 1));
-        __syncthreads();
-    };
 #ifdef VH_CLOCK
     unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-#if VH_ATTN_STATIC_SLOTS
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    int phase = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        if (phase == 0) one_tile(I0{}, I1{}, I2{}, tile);
-        else if (phase == 1) one_tile(I1{}, I2{}, I0{}, tile);
-        else one_tile(I2{}, I0{}, I1{}, tile);
-        phase = phase == 2 ? 0 : phase + 1;
-    }
-#else   // run-time slot numbers (A/B reference)
-    (void)one_tile;
     int ks0 = 0, ks1 = 1, ks2 = 2;
     if constexpr (PLACED) {
         bf16x8 PA[4], PB[4];
@@ -752,9 +722,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) PB[i][j] = (__bf16)0.f;
         kpre_l = kfrag(0, 1, 0, 1); kpre_h = kfrag(0, 1, 0, 0);
-#if VH_ATTN_PRIO
-        if (wv >= 4) __builtin_amdgcn_s_setprio(1);         // static priority for the later-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
-#endif
         // ring position of tile t = t mod 3 for K and V alike: K of tiles t, t+1, t+2 and V of tiles t, t+1, t-1 sit in slots (p, p+1, p+2) mod 3
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using IN = std::integral_constant<int, -1>;
@@ -818,7 +785,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_bf16x3_pipe(const AttnXK a) {
 #endif
         const int tmp = ks0; ks0 = ks1; ks1 = ks2; ks2 = tmp;
     }
-#endif
 #ifdef VH_CLOCK
     {
         const unsigned long long ck_m1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
