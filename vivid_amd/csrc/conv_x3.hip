@@ -25,9 +25,6 @@
 #define VH_CONV_TU 0
 #endif
 
-#ifndef VH_CONV_PLACED
-#define VH_CONV_PLACED 0     // 1: K-tile body written as scheduling regions of 4 MFMAs with the next tile's DMA pieces (pointer select + LDS-DMA) spread between them
-#endif
 #ifndef VH_EPI_PD
 #define VH_EPI_PD 1          // epilogue blocks whose residual / cvec values are in flight ahead of the one being written (3 measured the same)
 #endif
@@ -267,65 +264,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         }
     };
 
-    // Placed K-tile (16x16x32 only).  The compiler-scheduled loop issues the next tile's DMA as one block of ~55 VALU (pointer selection
-    // per slot) + 10 LDS-DMA instructions between two runs of ~46 MFMAs; the two waves of a SIMD pass the tile barrier together, reach
-    // that block together, and the matrix pipe idles under both (~11 % of the K loop, from the instruction stream and the in-kernel
-    // stamps).  Here the tile is 24 regions of 4 MFMAs (one product term of one 16-row block against the four column blocks), closed by
-    // sched_barrier(0); the first RA + RB regions each carry ONE DMA piece with its own pointer arithmetic, and the second batch of A
-    // fragments is read row by row as the first batch's rows retire (same 64 fragment registers).
-    auto piece = [&](int p, int st, int tap_, int cu, int bu, long long off) __attribute__((always_inline)) {
-        if (p < RA) {
-            const float4* src = pa[p];                       // tap-major: this tap's pointer, set when the tap changed
-            if constexpr (CHUNK) src = ((pmask[p] >> tap_) & 1u) ? pc[p] + off : zp;   // chunk-major: centre pointer + tap offset, or the zero page
-            glds16(src + cu, ldsA_w + (unsigned)st * (unsigned)(BM * 8 * 16) + p * 8192u);
-        } else {
-            const int j = p - RA;
-            glds16(bzero[j] ? zp : pb[j] + bu, ldsB_w + (unsigned)st * (unsigned)(BN * 8 * 16) + j * 8192u);
-        }
-    };
-    auto ktile_placed = [&](int st, auto nextc, int ntap, int ncc) __attribute__((always_inline)) {
-        constexpr bool NEXT = decltype(nextc)::value;
-        constexpr int NJ = NI * 2;
-        const int cu = ncc >> 2, bu = (ntap * a.cin_pad + ncc) >> 2;
-        long long off = 0;
-        if constexpr (CHUNK) {
-            const int dy = ntap / 3 - 1, dx = ntap - (ntap / 3) * 3 - 1;
-            off = (long long)(dy * a.w + dx) * (a.c0 >> 2);
-        }
-        // fragments: all of B (NJ column blocks, hi + lo), A as a rolling window of two 16-row blocks (a row block's registers take
-        // the block after next when its three product terms are done: 12 MFMAs = 384 pipe cycles of cover for the read)
-        constexpr int NR = 2 * MI;                            // 16-row blocks of this wave's tile
-        bf16x8 bh[NJ], bl[NJ], ah[2], al[2];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            bh[j] = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
-            bl[j] = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
-        }
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            ah[r] = *reinterpret_cast<const bf16x8*>(&sA[st][arow16 + r * 128 + u16h]);
-            al[r] = *reinterpret_cast<const bf16x8*>(&sA[st][arow16 + r * 128 + u16l]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-            for (int term = 0; term < 3; ++term) {
-                const int reg = r * 3 + term;
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    f32x4& c = acc16[r][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? al[r & 1] : ah[r & 1], term == 1 ? bl[j] : bh[j], c, 0, 0, 0);
-                }
-                if (NEXT && reg < RA + RB) piece(reg, st ^ 1, ntap, cu, bu, off);
-                if (term == 2 && r + 2 < NR) {
-                    ah[r & 1] = *reinterpret_cast<const bf16x8*>(&sA[st][arow16 + (r + 2) * 128 + u16h]);
-                    al[r & 1] = *reinterpret_cast<const bf16x8*>(&sA[st][arow16 + (r + 2) * 128 + u16l]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    };
-
     // ---- main loop: DMA of tile t+1 in flight during the MFMAs of tile t; one barrier per tile ------------
     const int KTall = a.k_pad / BK;
     const int kt0 = (int)((long long)KTall * ks / a.ksplit), KT = (int)((long long)KTall * (ks + 1) / a.ksplit) - kt0;
@@ -361,25 +299,6 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
     unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    if constexpr (VH_CONV_PLACED && M16) {
-        static_assert(MI * 6 >= RA + RB, "DMA pieces fit the regions");
-        int kt = 0;
-        for (; kt + 1 < KT; ++kt) {                           // tiles with a successor: its DMA pieces ride in this tile's regions
-            bool newtap = false;
-            if constexpr (chunk_major) {
-                if (++tap == 9) { tap = 0; cc += BK; }
-            } else {
-                cc += BK;
-                if (cc >= a.cin_pad) { cc = 0; ++tap; newtap = true; }
-            }
-            if (newtap) setup_tap(tap);                       // tap-major: coordinates change once per channel sweep (a clump, rare)
-            ktile_placed(kt & 1, std::true_type{}, tap, cc);
-            wait_dma();
-            __syncthreads();
-        }
-        ktile_placed(kt & 1, std::false_type{}, tap, cc);     // (peeled: with both forms inside one loop hipcc copies the accumulators between them)
-        __syncthreads();
-    } else
     for (int kt = 0; kt < KT; ++kt) {
         const int st = kt & 1;
         auto fetch_next = [&]() {
