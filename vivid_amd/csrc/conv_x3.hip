@@ -319,8 +319,12 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
         };
         if (!late) fetch_next();
         compute(st, [&]() { if (late) fetch_next(); });
+#if !(defined(VH_CONV_ABLATE) && (VH_CONV_ABLATE & 1))      // timing ablation builds (WRONG results): 1 = no wait for the DMA, 2 = no tile barrier
         wait_dma();                                        // this wave's DMA of tile kt+1 has landed ...
+#endif
+#if !(defined(VH_CONV_ABLATE) && (VH_CONV_ABLATE & 2))
         __syncthreads();                                   // ... and so has every other wave's
+#endif
     }
 #ifdef VH_CLOCK
     {
