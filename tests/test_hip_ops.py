@@ -441,13 +441,13 @@ def test_attention_headline_slice_vs_sdpa(ctx, b, heads, s, kl, d, nz):
 
 
 @pytest.mark.parametrize("kl", [65, 128, 129, 191, 192, 256, 320, 321, 384, 449, 512, 577, 640, 705])
-@pytest.mark.parametrize("m16", [1, 0])
-def test_attention_bounded_logits_tile_counts_and_s8_output(ctx, kl, m16):
-    """The 64-channel bounded-logit kernels (attn_fwd_x3_m16; knob attn_m16 = 0: the 32x32x16 form) walk the key tiles three per trip
+@pytest.mark.parametrize("m16,d", [(1, 64), (0, 64), (1, 32)])
+def test_attention_bounded_logits_tile_counts_and_s8_output(ctx, kl, m16, d):
+    """The bounded-logit kernels (attn_fwd_x3_m16<64 | 32>; knob attn_m16 = 0: the 32x32x16 form) walk the key tiles three per trip
     with the last <= 5 handled separately, ragged or not: every tile count from 2 to 12 with and without a key tail, ragged query
-    tail (s = 100), fp32 and S8 (bf16 hi/lo) outputs, against F.scaled_dot_product_attention."""
+    tail (s = 100 / 200), fp32 and S8 (bf16 hi/lo) outputs, against F.scaled_dot_product_attention."""
     from vivid_amd import _lib as L
-    b, heads, s, d = 1, 2, 100, 64
+    b, heads, s = 1, 2, 200 if d == 32 else 100          # (32-channel heads take the long-sequence kernels from s > 128)
     g = torch.Generator().manual_seed(kl)
     def unit(t):
         return t / t.square().mean(dim=-1, keepdim=True).sqrt()

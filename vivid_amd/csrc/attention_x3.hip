@@ -850,11 +850,14 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+template <int D>
 __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
-    constexpr int D = 64, NT = 512, KU = D / 4;
+    static_assert(D == 64 || D == 32, "head dims 64 and 32");
+    constexpr int NT = 512, KU = D / 4;
+    constexpr int KSTEPS = D / 32, MD = D / 16;              // 32-channel steps of QK^T; 16-channel blocks of O^T
     constexpr int K_UNITS = KU * KT, V_UNITS = D * 2 * (KT / 8);
     constexpr int KPT = K_UNITS / NT, VPT = V_UNITS / NT;
-    static_assert(KPT == 2 && VPT == 2, "two K and two V staging units per thread and tile");
+    static_assert(KPT == VPT && (KPT == 2 || KPT == 1), "K and V staging units per thread and tile");
     __shared__ uint4 sK[3][K_UNITS];
     __shared__ uint4 sV[3][V_UNITS];
 
@@ -866,13 +869,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
     const int qrow0 = bx * 256 + wv * 32 + li;               // this lane's query in block nq: qrow0 + 16 nq
 
     // Q fragments (B operand): query li of block nq, channels 32 kstep + 8 g .. +7
-    bf16x8 qh[2][2], ql[2][2];
+    bf16x8 qh[2][KSTEPS], ql[2][KSTEPS];
 #pragma unroll
     for (int nq = 0; nq < 2; ++nq) {
         const int qrow = qrow0 + 16 * nq;
         const float* Qb = a.q + ((size_t)bh * a.s + (qrow < a.s ? qrow : 0)) * D + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KSTEPS; ++ks) {
             float v[8];
             const float4 p0 = *reinterpret_cast<const float4*>(Qb + ks * 32);
             const float4 p1 = *reinterpret_cast<const float4*>(Qb + ks * 32 + 4);
@@ -884,9 +887,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
             split8(v, qh[nq][ks], ql[nq][ks]);
         }
     }
-    f32x4 o[4][2];                                           // O^T: channels 16 md + 4 g + r of query (nq, li)
+    f32x4 o[MD][2];                                           // O^T: channels 16 md + 4 g + r of query (nq, li)
 #pragma unroll
-    for (int md = 0; md < 4; ++md)
+    for (int md = 0; md < MD; ++md)
 #pragma unroll
         for (int nq = 0; nq < 2; ++nq)
 #pragma unroll
@@ -958,14 +961,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
 
     // fragment addresses: per-lane LDS byte addresses in slot 0 (K: first 32 keys of the tile); slot, sub-tile and 16-channel block
     // are compile-time offsets of the ds_read
-    unsigned koff[2][2][2], voff[2][2];                      // [mk][kstep][hi, lo]; [keys 0-31 / 32-63][hi, lo]
+    unsigned koff[2][KSTEPS][2], voff[2][2];                      // [mk][kstep][hi, lo]; [keys 0-31 / 32-63][hi, lo]
     {
         const unsigned kbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sK[0][0];
         const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&sV[0][0];
 #pragma unroll
         for (int mk = 0; mk < 2; ++mk)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < KSTEPS; ++ks)
 #pragma unroll
                 for (int lohi = 0; lohi < 2; ++lohi) {
                     const int key = (li & 7) + 8 * mk + 16 * (li >> 3);
@@ -1016,7 +1019,10 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
         float e[16];
         unsigned hw[8], lw[8];
         float t0[8], t1[8];
-        bf16x8 kf[4][2], vf[4][2];                           // [block of 6 MFMAs][hi, lo]
+        // MFMA lists: QK^T blocks (mk, kstep) of 6 = {lo.hi, lo.hi | hi.lo, hi.lo | hi.hi, hi.hi} for query blocks 0, 1; P.V blocks of 6 per
+        // 16 channels.  D = 64: 24 + 24, one of each per region; D = 32: 12 + 12, alternating regions.
+        constexpr int NQB = 2 * KSTEPS, NPB = MD;             // blocks of 6 MFMAs
+        bf16x8 kf[NQB][2], vf[NPB][2];                        // [block][hi, lo]
         kf[0][0] = kpre[0]; kf[0][1] = kpre[1]; vf[0][0] = vpre[0]; vf[0][1] = vpre[1];
         auto cvt2 = [](float x, float y) __attribute__((always_inline)) -> unsigned {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -1032,11 +1038,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
         };
         static_for<0, 24>([&](auto rc) __attribute__((always_inline)) {
             constexpr int R = decltype(rc)::value;
-            constexpr int blk = R / 6, j = R % 6, nq = j & 1;
-            // fragment reads, issued five regions ahead of their first MFMA
-            if constexpr (j == 1 && blk < 3) {
-                constexpr int nb = blk + 1;
-                kf[nb][0] = kfrag(NSL, NKS, nb >> 1, nb & 1, 0); kf[nb][1] = kfrag(NSL, NKS, nb >> 1, nb & 1, 1);
+            constexpr bool HAS_Q = D == 64 || (R & 1) == 0, HAS_P = D == 64 || (R & 1) == 1;
+            constexpr int QI = D == 64 ? R : R / 2, PI = D == 64 ? R : R / 2;
+            // fragment reads, issued five MFMAs of their list ahead of the block's first one
+            if constexpr (HAS_Q && QI % 6 == 1 && QI / 6 + 1 < NQB) {
+                constexpr int nb = QI / 6 + 1;
+                kf[nb][0] = kfrag(NSL, NKS, nb / KSTEPS, nb % KSTEPS, 0); kf[nb][1] = kfrag(NSL, NKS, nb / KSTEPS, nb % KSTEPS, 1);
+            }
+            if constexpr (HAS_P && PI % 6 == 1 && PI / 6 + 1 < NPB) {
+                constexpr int nb = PI / 6 + 1;
                 vf[nb][0] = vfrag(VSL, VKS, nb, 0); vf[nb][1] = vfrag(VSL, VKS, nb, 1);
             }
             if constexpr (R == 19) {
@@ -1044,18 +1054,17 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
                 vpre[0] = vfrag(PVSL, PVKS, 0, 0); vpre[1] = vfrag(PVSL, PVKS, 0, 1);
             }
             if constexpr (SK >= 0 && R == 4) sK[SK][ksl[0]] = rk[0];
-            if constexpr (SK >= 0 && R == 8) sK[SK][ksl[1]] = rk[1];
+            if constexpr (SK >= 0 && R == 8 && KPT == 2) sK[SK][ksl[KPT - 1]] = rk[KPT - 1];
             if constexpr (SV >= 0 && R == 12) sV[SV][vsl[0]] = rv[0];
-            if constexpr (SV >= 0 && R == 16) sV[SV][vsl[1]] = rv[1];
-            // QK^T: block = (mk, kstep); j: lo.hi, lo.hi | hi.lo, hi.lo | hi.hi, hi.hi for query blocks 0, 1
-            {
-                constexpr int mk = blk >> 1, kstep = blk & 1;
+            if constexpr (SV >= 0 && R == 16 && VPT == 2) sV[SV][vsl[VPT - 1]] = rv[VPT - 1];
+            if constexpr (HAS_Q) {
+                constexpr int blk = QI / 6, j = QI % 6, nq = j & 1, mk = blk / KSTEPS, kstep = blk % KSTEPS;
                 const bf16x8 afrag = kf[blk][j < 2 ? 1 : 0];
                 const bf16x8 bfrag = (j == 2 || j == 3) ? ql[nq][kstep] : qh[nq][kstep];
                 snext[mk][nq] = VH_MFMA16(afrag, bfrag, (kstep == 0 && j < 2) ? zero : snext[mk][nq]);
             }
-            // P.V: block = 16 channels md
-            {
+            if constexpr (HAS_P) {
+                constexpr int blk = PI / 6, j = PI % 6, nq = j & 1;
                 const bf16x8 afrag = vf[blk][j < 2 ? 1 : 0];
                 const bf16x8 bfrag = (j == 2 || j == 3) ? pin[nq][1] : pin[nq][0];
                 o[blk][nq] = VH_MFMA16(afrag, bfrag, o[blk][nq]);
@@ -1102,7 +1111,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
         for (int nq = 0; nq < 2; ++nq) {
             f32x4 acc = zero;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < KSTEPS; ++ks) {
                 const bf16x8 kh = kfrag(0, 0, mk, ks, 0), kl_ = kfrag(0, 0, mk, ks, 1);
                 acc = VH_MFMA16(kl_, qh[nq][ks], acc);
                 acc = VH_MFMA16(kh, ql[nq][ks], acc);
@@ -1162,7 +1171,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
     {
         const int vs = (ntiles + 2) % 3;
 #pragma unroll
-        for (int md = 0; md < 4; ++md) {
+        for (int md = 0; md < MD; ++md) {
             const bf16x8 vh = *(lds_frag_ptr)(size_t)(voff[1][0] + (unsigned)(vs * (V_UNITS * 16) + md * 4096));
             const bf16x8 vl = *(lds_frag_ptr)(size_t)(voff[1][1] + (unsigned)(vs * (V_UNITS * 16) + md * 4096));
 #pragma unroll
@@ -1194,7 +1203,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
             // S8: per 8 channels [hi x8 | lo x8] bf16; this lane owns half a chunk (4 channels): two 8-byte stores
             unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + (((size_t)b * a.s + qrow) * a.c + hd * D) * 2;
 #pragma unroll
-            for (int md = 0; md < 4; ++md) {
+            for (int md = 0; md < MD; ++md) {
                 unsigned h[4], lo4[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1209,7 +1218,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_x3_m16(const AttnXK a) {
         } else {
             float* op = a.out + ((size_t)b * a.s + qrow) * a.c + hd * D;
 #pragma unroll
-            for (int md = 0; md < 4; ++md) {
+            for (int md = 0; md < MD; ++md) {
                 float4 w;
                 w.x = o[md][nq][0] * inv; w.y = o[md][nq][1] * inv; w.z = o[md][nq][2] * inv; w.w = o[md][nq][3] * inv;
                 *reinterpret_cast<float4*>(op + md * 16 + 4 * g) = w;
@@ -1377,7 +1386,8 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     const double bytes = 4.0 * bhd * a.d * (2.0 * a.s + 2.0 * a.kl);
     const bool m16 = vh_knob(VH_KNOB_ATTN_M16) != 0;        // knob "attn_m16" = 0: the 32x32x16 placed kernel (A/B)
     return vh_dispatch(ctx, VH_TAG_ATTN, flops, bytes, [k, d, nw, pipe, nomax, m16, grid](hipStream_t s) -> int {
-        if (pipe && d == 64 && nomax && m16) hipLaunchKernelGGL(attn_fwd_x3_m16, grid, dim3(512), 0, s, k);
+        if (pipe && d == 64 && nomax && m16) hipLaunchKernelGGL(attn_fwd_x3_m16<64>, grid, dim3(512), 0, s, k);
+        else if (pipe && nomax && m16) hipLaunchKernelGGL(attn_fwd_x3_m16<32>, grid, dim3(512), 0, s, k);
         else if (pipe && d == 64 && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64, true>), grid, dim3(512), 0, s, k);
         else if (pipe && d == 64) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<64>), grid, dim3(512), 0, s, k);
         else if (pipe && nomax) hipLaunchKernelGGL((attn_fwd_bf16x3_pipe<32, true>), grid, dim3(512), 0, s, k);
