@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 evidence for one round (run on the GPU box through gpurun):  bash tools/profile_round.sh r02_c2_bf16x3_v9
+# rocprofv3 evidence for one round (run on the GPU box through gpurun):  bash tools/profile_round.sh r02_c2_bf16x3_v11
 # 1. kernel trace + stats of the bench command, 2./3. FETCH_SIZE / WRITE_SIZE in passes of their own (MI355X_MICROARCH.md: TCC slots),
 # 4. per-layer tables of the four BASELINE workloads.  Raw output under gpurun_out/prof_<tag>/, summaries under profiles/.
 set -e
