@@ -37,7 +37,7 @@ extern "C" {
 typedef struct vh_ctx vh_ctx;
 typedef struct vh_plan vh_plan;
 
-#define VH_ABI_VERSION 2
+#define VH_ABI_VERSION 3
 int vh_abi_version(void);                                /* == VH_ABI_VERSION of the header the library was built from */
 const char* vh_last_error(void);
 
@@ -50,8 +50,17 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * every (batch, head) of the bf16x3 attention on one XCD, 0 keeps the plain workgroup order (A/B timing in one process);
  * "attn_m16": 1 (default) runs 64-channel bounded-logit attention on the 16x16x32 MFMA kernel, 0 on the 32x32x16 one;
  * "dbg_lo" / "dbg_hi": the two halves of a device pointer that receives the clock stamps of the diagnostic builds
- * (-DVH_CLOCK, tools/clock_probe.py) - the product build never writes to it.  Returns VH_EINVAL for an unknown name. */
+ * (-DVH_CLOCK, tools/clock_probe.py) - the product build never writes to it;
+ * "conv_korder": -1 (default) K order of the 3x3 bf16x3 convolutions by input size / vh_conv_args.korder, 0 tap-major, 1 chunk-major;
+ * "conv_stagger": -1 (default) vh_conv_args.stagger decides, 0 never, 1 always;
+ * "attn_pipe": 1 (default) software-pipelined bf16x3 attention kernels for long sequences, 0 the plain ones;
+ * "attn_nomax": 1 (default) bounded-logit attention keeps no running maximum, 0 keeps it.
+ * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);
+
+/* 0 for a product build.  Non-zero: some translation unit was compiled with -DVH_DIAG (clock stamps or timing ablations that
+ * compute WRONG results on purpose; `make variant`) - the Python binding refuses to load such a library as libvivid_hip.so. */
+int vh_diag_flags(void);
 
 /* Per-kernel timing with HIP events on the launch stream (bench.py's roofline line).
  * While enabled, every launch (direct or replayed) is bracketed by two events and carries its
@@ -412,6 +421,7 @@ enum { VH_U8 = 0, VH_F32 = 1 };
 typedef struct {
     const void* x; const void* y; int images; size_t elems; int dtype;
     double* acc;
+    double* per_image;         /* scratch, `images` doubles: per-image values, folded into acc[0] in index order (bit-reproducible) */
 } vh_psnr_args;
 int vh_psnr_sum(vh_ctx* ctx, const vh_psnr_args* a);
 

@@ -17,6 +17,9 @@ import torch  # noqa: E402
 from vivid_amd import _lib as L  # noqa: E402
 
 
+KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1}
+
+
 def load(suffix):
     path = os.path.join(ROOT, "vivid_amd", f"libvivid_hip{'_' + suffix if suffix else ''}.so")
     L._lib, L.LIB_PATH = None, path
@@ -98,7 +101,7 @@ def main():
         for _ in range(k):
             ctx.call(op, a)
         for kk in knobs:                       # back to the defaults of the next variant's library
-            ctx._L.vh_set_knob(kk.encode(), {"attn_xcd": 1}.get(kk, 0))
+            ctx._L.vh_set_knob(kk.encode(), KNOB_DEFAULTS.get(kk, 0))
 
     for r in runs:
         launch(r, 2)

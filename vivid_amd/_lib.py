@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIVID_HIP_LIB") or os.path.join(_HERE, "libvivid_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
-ABI_VERSION = 2          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
+ABI_VERSION = 3          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
 
 
 class VividHipError(RuntimeError):
@@ -124,7 +124,7 @@ class MomentsArgs(C.Structure):
 
 class PsnrArgs(C.Structure):
     _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("images", C.c_int), ("elems", C.c_size_t), ("dtype", C.c_int),
-                ("acc", C.c_void_p)]
+                ("acc", C.c_void_p), ("per_image", C.c_void_p)]
 
 
 class CodecArgs(C.Structure):
@@ -159,7 +159,7 @@ OPS = {
     "vh_nonzero_flag": NonzeroArgs, "vh_resample": ResampleArgs, "vh_moments": MomentsArgs, "vh_psnr_sum": PsnrArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
-CONTROL = ["vh_abi_version", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob",
+CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
            "vh_plan_begin", "vh_plan_end", "vh_plan_abort", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
@@ -180,6 +180,10 @@ def lib():
     if L.vh_abi_version() != ABI_VERSION:
         raise VividHipError(f"{LIB_PATH} was built from another version of include/vivid_hip.h (library ABI {L.vh_abi_version()}, "
                             f"bindings {ABI_VERSION}): rebuild it with `make -C vivid_amd/csrc`")
+    L.vh_diag_flags.restype = C.c_int
+    if L.vh_diag_flags() and not os.environ.get("VIVID_HIP_LIB") and os.path.basename(LIB_PATH) == "libvivid_hip.so":
+        raise VividHipError(f"{LIB_PATH} is a DIAGNOSTIC build (vh_diag_flags = {L.vh_diag_flags()}: clock stamps or timing ablations "
+                            f"that compute wrong results): rebuild the product library with `make -C vivid_amd/csrc clean all`")
     L.vh_last_error.restype = C.c_char_p
     L.vh_ctx_create.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.vh_ctx_destroy.argtypes = [C.c_void_p]

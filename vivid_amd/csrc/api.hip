@@ -6,8 +6,8 @@ std::string& vh_err() {
     return e;
 }
 
-static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0, 1};
-static const char* const g_knob_names[VH_NUM_KNOBS] = {"attn_xcd", "dbg_lo", "dbg_hi", "attn_m16"};
+static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0, 1, -1, -1, 1, 1};
+static const char* const g_knob_names[VH_NUM_KNOBS] = {"attn_xcd", "dbg_lo", "dbg_hi", "attn_m16", "conv_korder", "conv_stagger", "attn_pipe", "attn_nomax"};
 
 int vh_knob(int id) { return (id >= 0 && id < VH_NUM_KNOBS) ? g_knobs[id] : 0; }
 
@@ -19,6 +19,12 @@ extern "C" int vh_set_knob(const char* name, int value) {
 }
 
 extern "C" int vh_abi_version(void) { return VH_ABI_VERSION; }
+
+// bit i set = translation unit i was compiled with -DVH_DIAG (stamps / timing ablations): not a product library
+int vh_diag_conv3();
+int vh_diag_conv1();
+int vh_diag_attn();
+extern "C" int vh_diag_flags(void) { return VH_DIAG_FLAG | (vh_diag_conv3() << 1) | (vh_diag_conv1() << 2) | (vh_diag_attn() << 3); }
 
 extern "C" const char* vh_last_error(void) { return vh_err().c_str(); }
 

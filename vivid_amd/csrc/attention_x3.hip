@@ -20,7 +20,6 @@
 // The running max is only raised (and O rescaled) when some query's max grew by more than 2^8
 // (fp32 accumulators: no precision is lost by the deferred scale).
 #include "ctx.h"
-#include <cstdlib>
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1354,6 +1353,8 @@ extern "C" int vh_qkv_split_x3(vh_ctx* ctx, const vh_qkv_split_args* p) {
     });
 }
 
+int vh_diag_attn() { return VH_DIAG_FLAG; }
+
 extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_attention_x3: null args");
     const vh_attention_args a = *p;
@@ -1372,10 +1373,10 @@ extern "C" int vh_attention_x3(vh_ctx* ctx, const vh_attention_args* p) {
     // slower: every workgroup stages its own copy of the K/V stream).
     // (64-channel heads always take the 8-wave form: its 4-wave instantiation needs more than 256 VGPRs and spills)
     const int nw = (a.s > 128 || a.d == 64) ? 8 : 4;
-    static const bool use_pipe = !(getenv("VIVID_ATTN_PIPE") && atoi(getenv("VIVID_ATTN_PIPE")) == 0);
+    const bool use_pipe = vh_knob(VH_KNOB_ATTN_PIPE) != 0;
     const bool pipe = use_pipe && nw == 8 && a.kl > KT;
     VH_REQUIRE(a.logit_bound >= 0.f, "vh_attention_x3: negative logit_bound");
-    static const bool nomax_on = !(getenv("VIVID_ATTN_NOMAX") && atoi(getenv("VIVID_ATTN_NOMAX")) == 0);
+    const bool nomax_on = vh_knob(VH_KNOB_ATTN_NOMAX) != 0;
     const bool nomax = nomax_on && a.logit_bound > 0.f && a.logit_bound <= 64.f;
     k.nx = (a.s + nw * 32 - 1) / (nw * 32);
     k.ny = a.b * a.heads;

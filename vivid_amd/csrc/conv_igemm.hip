@@ -248,6 +248,9 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(a.k_pad == a.taps * a.cin_pad, "vh_conv: k_pad %d != taps*cin_pad %d", a.k_pad, a.taps * a.cin_pad);
     VH_REQUIRE(a.zeros && vh_aligned16(a.zeros) && a.zeros_bytes >= (size_t)a.cin_pad * 4 + 64, "vh_conv: zero page missing or smaller than cin_pad*4+64 bytes");
     VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.wt), "vh_conv: source/weight pointers must be 16-byte aligned");
+    // the epilogues read the residual / cvec rows and write the fp32 / S8 outputs as 16-byte vectors whenever cout % 4 == 0
+    VH_REQUIRE(a.cout % 4 != 0 || (vh_aligned16(a.out) && vh_aligned16(a.out_s8) && vh_aligned16(a.res) && (a.cvec_ld % 4 != 0 || vh_aligned16(a.cvec))),
+               "vh_conv: with cout %% 4 == 0, out, out_s8, res (and cvec when cvec_ld %% 4 == 0) must be 16-byte aligned");
     VH_REQUIRE(!a.up || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: up needs even output size");
     VH_REQUIRE(a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU, "vh_conv: bad prologue");
     VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_QKV, "vh_conv: bad epilogue");

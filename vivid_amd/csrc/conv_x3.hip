@@ -16,7 +16,6 @@
 #include "conv_common.h"
 #include <algorithm>
 #include <type_traits>
-#include <cstdlib>
 
 // The Makefile builds this file twice: VH_CONV_TU=9 (the 3x3 kernels, the split-K reducer and the dispatcher; compiled with
 // -mllvm -amdgpu-sched-strategy=iterative-ilp, +2.0..2.8 % on the 3x3 shapes of C2) and VH_CONV_TU=1 (the 1x1 kernels, default
@@ -552,7 +551,11 @@ void vh_conv_x3_launch_1tap(const vhconv::ConvK& k, int cfg, unsigned grid, hipS
 void vh_conv_x3_launch_1tap(const vhconv::ConvK& k, int cfg, unsigned grid, hipStream_t s);
 #endif
 
+#if VH_CONV_TU != 9
+int vh_diag_conv1() { return VH_DIAG_FLAG; }
+#endif
 #if VH_CONV_TU != 1
+int vh_diag_conv3() { return VH_DIAG_FLAG; }
 // Entry used by vh_conv for prec == VH_PREC_BF16X3 && kernel == VH_CONV_GLDS (arguments already validated).
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
@@ -594,15 +597,15 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // chunk-major K order when the input does not stay in the 256 MB Infinity Cache either: with tap-major order each tap's
     // re-read then comes from HBM.  Measured: +7..10 % at 256x256 (0.5-1 GB inputs), +3..4 % at 128x128 (0.27-0.54 GB),
     // +1.6 % at 0.2 GB, -2 % at 67 MB (the per-K-tile pointer selection costs VALU and buys nothing there).
-    // vh_conv_args.korder overrides the size rule; VIVID_CONV_KORDER (0 tap / 1 chunk) overrides both (A/B runs).
-    static const int korder_env = getenv("VIVID_CONV_KORDER") ? atoi(getenv("VIVID_CONV_KORDER")) : -1;
+    // vh_conv_args.korder overrides the size rule; the process-wide knob "conv_korder" (0 tap / 1 chunk) overrides both (A/B runs).
+    const int korder_env = vh_knob(VH_KNOB_CONV_KORDER);
     const bool big_input = (double)M * a.cin_pad * 4.0 > 1.5e8;
     const int korder_arg = a.korder == VH_KORDER_TAP ? 0 : a.korder == VH_KORDER_CHUNK ? 1 : (big_input ? 1 : 0);
     k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : korder_arg) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
     const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
-    static const int stagger_env = getenv("VIVID_CONV_STAGGER") ? atoi(getenv("VIVID_CONV_STAGGER")) : -1;
+    const int stagger_env = vh_knob(VH_KNOB_CONV_STAGGER);
     k.stagger = stagger_env >= 0 ? stagger_env : (a.stagger == 1 ? 1 : 0);       // default: off (see the kernel's note on `late`)
     const bool chunk = k.korder != 0;
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, chunk, grid](hipStream_t s) -> int {

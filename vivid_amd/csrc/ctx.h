@@ -40,7 +40,12 @@ struct vh_ctx {
 int vh_run_op(vh_ctx* ctx, const vh_op& op);
 
 // process-wide scheduling knobs (vh_set_knob)
-enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATTN_M16 = 3, VH_NUM_KNOBS = 4 };
+enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATTN_M16 = 3,
+       VH_KNOB_CONV_KORDER = 4,      // -1: by input size / vh_conv_args.korder (default); 0 tap-major, 1 chunk-major (A/B runs)
+       VH_KNOB_CONV_STAGGER = 5,     // -1: vh_conv_args.stagger (default); 0 never, 1 always
+       VH_KNOB_ATTN_PIPE = 6,        // 0: plain instead of software-pipelined attention kernels
+       VH_KNOB_ATTN_NOMAX = 7,       // 0: keep the running maximum although logit_bound allows dropping it
+       VH_NUM_KNOBS = 8 };
 int vh_knob(int id);
 // device buffer for the stamps of diagnostic builds (-DVH_CLOCK), set through the knobs "dbg_lo"/"dbg_hi"; null otherwise
 inline unsigned long long* vh_debug_ptr() {
@@ -83,3 +88,15 @@ inline int vh_dispatch(vh_ctx* ctx, int tag, double flops, double bytes, F&& lau
 }
 
 inline bool vh_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Diagnostic switches (-DVH_CLOCK stamps, -DVH_CONV_ABLATE / -DVH_ATTN_ABLATE timing ablations that compute WRONG results) compile
+// only together with -DVH_DIAG, which `make` gives to `make variant` builds alone; a translation unit built with it reports so
+// through vh_diag_flags(), the Python binding refuses such a library as the product, and __graft_entry__.build() asserts 0.
+#if (defined(VH_CLOCK) || defined(VH_CONV_ABLATE) || defined(VH_ATTN_ABLATE)) && !defined(VH_DIAG)
+#error "VH_CLOCK / VH_CONV_ABLATE / VH_ATTN_ABLATE are diagnostic switches: build them with `make variant ... DEFS='-DVH_DIAG ...'`, never into libvivid_hip.so"
+#endif
+#ifdef VH_DIAG
+#define VH_DIAG_FLAG 1
+#else
+#define VH_DIAG_FLAG 0
+#endif

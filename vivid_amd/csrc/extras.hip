@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256) void moments_k(vh_moments_args a) {
 }
 
 // ---------------------------------------------------------------- PSNR (calculate_metrics.py:147)
-// acc[0] += sum over images of 10 log10(255^2 / mean((x - y)^2)); one workgroup per image, uint8 or fp32 inputs
+// per_image[i] = 10 log10(255^2 / mean((x_i - y_i)^2)); one workgroup per image, uint8 or fp32 inputs.  The per-image values are
+// then added to acc[0] by ONE lane in index order (psnr_fold_k): the accumulator is bit-reproducible from run to run, which a
+// double atomicAdd in arrival order was not.
 template <class T>
-__global__ __launch_bounds__(256) void psnr_k(const T* x, const T* y, long long elems, double* acc) {
+__global__ __launch_bounds__(256) void psnr_k(const T* x, const T* y, long long elems, double* per_image) {
     __shared__ double red[4];
     const int t = threadIdx.x;
     const T* xi = x + (size_t)blockIdx.x * elems;
@@ -132,7 +134,15 @@ __global__ __launch_bounds__(256) void psnr_k(const T* x, const T* y, long long 
     __syncthreads();
     if (t == 0) {
         const double mse = (red[0] + red[1] + red[2] + red[3]) / (double)elems;
-        atomicAdd(acc, 10.0 * log10(255.0 * 255.0 / mse));
+        per_image[blockIdx.x] = 10.0 * log10(255.0 * 255.0 / mse);
+    }
+}
+
+__global__ void psnr_fold_k(const double* per_image, int images, double* acc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = acc[0];
+        for (int i = 0; i < images; ++i) s += per_image[i];
+        acc[0] = s;
     }
 }
 
@@ -186,15 +196,16 @@ extern "C" int vh_moments(vh_ctx* ctx, const vh_moments_args* p) {
 extern "C" int vh_psnr_sum(vh_ctx* ctx, const vh_psnr_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_psnr_sum: null args");
     const vh_psnr_args a = *p;
-    VH_REQUIRE(a.x && a.y && a.acc, "vh_psnr_sum: null tensor");
+    VH_REQUIRE(a.x && a.y && a.acc && a.per_image, "vh_psnr_sum: null tensor");
     VH_REQUIRE(a.images > 0 && a.elems > 0 && (a.dtype == VH_U8 || a.dtype == VH_F32), "vh_psnr_sum: bad arguments");
     return vh_dispatch(ctx, VH_TAG_SAMPLER, 0.0, (a.dtype == VH_U8 ? 2.0 : 8.0) * a.images * (double)a.elems, [a](hipStream_t s) -> int {
         if (a.dtype == VH_U8)
             hipLaunchKernelGGL(psnr_k<unsigned char>, dim3(a.images), dim3(256), 0, s, static_cast<const unsigned char*>(a.x),
-                               static_cast<const unsigned char*>(a.y), (long long)a.elems, a.acc);
+                               static_cast<const unsigned char*>(a.y), (long long)a.elems, a.per_image);
         else
             hipLaunchKernelGGL(psnr_k<float>, dim3(a.images), dim3(256), 0, s, static_cast<const float*>(a.x),
-                               static_cast<const float*>(a.y), (long long)a.elems, a.acc);
+                               static_cast<const float*>(a.y), (long long)a.elems, a.per_image);
+        hipLaunchKernelGGL(psnr_fold_k, dim3(1), dim3(64), 0, s, a.per_image, a.images, a.acc);
         return vh_check_launch("psnr_k");
     });
 }

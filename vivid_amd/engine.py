@@ -624,10 +624,15 @@ class Engine:
             try:
                 io = self._walk(mode, B, has_cond, want_logvar, fill if emit else None)
             except BaseException:
-                # an op was refused (unsupported shape, alignment): leave the context usable and the real error visible
-                if emit and self.hook is None:
-                    self.ctx.plan_abort()
+                # an op was refused (unsupported shape, alignment): leave the engine and the context usable and the real error
+                # visible - state first, then the abort, whose own failure (e.g. a sticky HIP error) must not replace the cause
+                recording = emit and self.hook is None
                 self._emit, self._A, self._backing = False, None, None
+                if recording:
+                    try:
+                        self.ctx.plan_abort()
+                    except Exception:
+                        pass
                 raise
             if not emit:
                 peak = self._A.peak

@@ -157,8 +157,14 @@ def generate_images_nvs(
     depth_fn: Optional[Callable] = None,            # images [N,3,H,W] in [0,255] -> depth map [N,1,H,W]
     dual_source: Optional[bool] = None,             # None = take it from net.dual_source
     rng_device=None,                                # device of the per-seed generators (default: `device`, as the reference)
+    resize_antialias: bool = True,                  # the three torchvision resizes of the cascade (:299-302, :322), see below
     **sampler_kwargs,
 ):
+    """``resize_antialias``: the reference calls ``torchvision.transforms.functional.resize(tensor, size)`` without naming
+    ``antialias``; which filter that is depends on the torchvision version ("pytorch > 2" admits both): torchvision >= 0.17
+    defaults to antialias=True for tensors, 0.15-0.16 to False with a warning.  This build follows current torchvision (True);
+    pass False to reproduce a run made with an older torchvision.  It matters only for the 4x DOWN-scale of the SR net's
+    conditioning image (:299-302); for the up-scales the two filters coincide."""
     device = torch.device(device)
     net, gnet, sr_model, encoder = _resolve_networks(net, gnet, sr_model, encoder, device, dual_source)
     if data is None:
@@ -185,7 +191,7 @@ def generate_images_nvs(
         kw = dict(sampler_kwargs)
         if net_is_sr:                                                                         # :297-303: blurred target as conditioning
             tgt_lat = encoder.encode_latents(r.tgt.to(device))
-            kw["conditioning_image"] = resize(resize(tgt_lat, tgt_lat.shape[-1] // 4), tgt_lat.shape[-1])
+            kw["conditioning_image"] = resize(resize(tgt_lat, tgt_lat.shape[-1] // 4, resize_antialias), tgt_lat.shape[-1], resize_antialias)
         latents = sampler_fn(net=net, src=src, noise=r.noise, labels=r.labels, gnet=gnet,
                              randn_like=b.churn_noise_fn(rnd), **kw)                         # :305-307
         r.images = encoder.decode(latents)
@@ -197,7 +203,7 @@ def generate_images_nvs(
         rnd = b.generator()                                                                   # the same seeds start over (:319)
         r.noise = b.noise(rnd, [sr_model.img_channels, sr_model.img_resolution, sr_model.img_resolution])
         r.labels = b.rows(b.field("sr_geometry")).to(device)
-        low_res = resize(latents, sr_src.shape[-1])                                           # :322
+        low_res = resize(latents, sr_src.shape[-1], resize_antialias)                         # :322
         sr_latents = sampler_fn(net=sr_model, src=sr_src, noise=r.noise, labels=r.labels, gnet=sr_model,
                                 conditioning_image=low_res, randn_like=b.churn_noise_fn(rnd), **sr_kwargs)
         r.images = encoder.decode(sr_latents)

@@ -27,10 +27,17 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Iterable, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
 from . import _lib as L
+from .generate import EasyDict
+
+def _rank() -> int:
+    return torch.distributed.get_rank() if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
+
 
 DETECTOR_METRICS = ("fid", "fd_dinov2")
 STAT_METRICS = DETECTOR_METRICS + tuple("joint_" + m for m in DETECTOR_METRICS)
@@ -123,9 +130,10 @@ class MomentBank:
             u8 = images.dtype == torch.uint8 and tgt.dtype == torch.uint8
             x = images.contiguous() if u8 else images.to(torch.float32).contiguous()
             y = tgt.contiguous() if u8 else tgt.to(torch.float32).contiguous()
+            per_image = torch.empty(n, dtype=torch.float64, device=self.device)     # folded into acc in index order: reproducible
             with torch.cuda.device(self.device):
                 self._context().call("vh_psnr_sum", L.PsnrArgs(x=x.data_ptr(), y=y.data_ptr(), images=n, elems=x[0].numel(),
-                                                              dtype=0 if u8 else 1, acc=acc.data_ptr()))
+                                                              dtype=0 if u8 else 1, acc=acc.data_ptr(), per_image=per_image.data_ptr()))
         else:
             d = images.to(torch.float32) - tgt.to(torch.float32)
             acc += (10 * torch.log10(255.0 ** 2 / (d * d).mean(dim=(1, 2, 3)))).to(torch.float64).sum()
@@ -172,20 +180,18 @@ class MomentBank:
         return gen, ref
 
 
-class _Record(dict):
-    """Per-batch result with attribute access (the reference yields dnnlib.EasyDict records)."""
-    __getattr__ = dict.__getitem__
-    __setattr__ = dict.__setitem__
-
-
 def calculate_stats_for_iterable_nvs(image_iter: Iterable, detectors: Dict[str, Callable],
-                                     metrics: Sequence[str] = ("fid", "joint_fid", "psnr"), device="cuda"):
+                                     metrics: Sequence[str] = ("fid", "joint_fid", "psnr"), device="cuda", dest_path=None):
     """Feature statistics over the records of ``generate_images_nvs`` (fields ``images``, ``tgt``, ``src``: NCHW, [0,255]).
 
     Returns an iterable with a length; iterating it yields ``(r, ref)`` per batch (``stats=None, images, batch_idx,
     num_batches, num_images``), and on the last batch ``r.stats`` / ``ref.stats`` hold the all_reduced statistics in the
     reference's format.  ``detectors`` maps "fid" / "fd_dinov2" to feature extractors; a ``joint_*`` metric needs its base
-    metric (calculate_metrics.py:143-145)."""
+    metric (calculate_metrics.py:143-145).  Records are ``generate.EasyDict`` (missing attribute -> AttributeError, as dnnlib's).
+    ``num_images`` of the intermediate records is this rank's running count (the reference all_reduces it every batch for its
+    progress bar, calculate_metrics.py:224-228; here nothing is exchanged before the last batch, whose records carry the global
+    counts).  ``dest_path``: rank 0 pickles the generated-side statistics there after the last batch (the reference calls an
+    undefined ``save_stats`` at :239-240; the pickle of the stats dict is what upstream EDM2's function of that name writes)."""
     metrics = list(metrics)
     for m in metrics:
         if m.startswith("joint_") and m[len("joint_"):] not in metrics:
@@ -210,10 +216,15 @@ def calculate_stats_for_iterable_nvs(image_iter: Iterable, detectors: Dict[str, 
                 bank.add_counts(images.shape[0], tgt.shape[0])
                 seen += images.shape[0]
             common = dict(stats=None, images=images, batch_idx=batch_idx, num_batches=num_batches, num_images=seen)
-            r, ref = _Record(common), _Record(common)
+            r, ref = EasyDict(common), EasyDict(common)
             if batch_idx == num_batches - 1:
                 r.stats, ref.stats = bank.all_reduce().finalize(want_psnr)
                 r.num_images, ref.num_images = r.stats["num_images"], ref.stats["num_images"]
+                if dest_path is not None and _rank() == 0:
+                    import pickle
+                    os.makedirs(os.path.dirname(os.path.abspath(dest_path)), exist_ok=True)
+                    with open(dest_path, "wb") as f:
+                        pickle.dump(r.stats, f)
             yield r, ref
 
     class _Stats:

@@ -34,12 +34,35 @@ from .weights import state_dict_shapes
 
 
 class _Node(torch.nn.Module):
-    """Parameter container reproducing the reference's module tree (for state_dict key names)."""
+    """Parameter container reproducing the reference's module tree (for state_dict key names).  Every node of one net shares
+    `_epoch` (a one-element list): any tensor assigned, registered or deleted anywhere in the tree bumps it, which is what tells
+    NVPrecond that the weights it prepared may be stale (EMA swaps by assignment, parametrisations, ...)."""
+
+    def __init__(self, epoch=None):
+        super().__init__()
+        object.__setattr__(self, "_epoch", epoch if epoch is not None else [0])
 
     def child(self, name: str) -> "_Node":
         if name not in self._modules:
-            self.add_module(name, _Node())
+            self.add_module(name, _Node(self._epoch))
         return self._modules[name]
+
+    def __setattr__(self, name, value):
+        if isinstance(value, torch.Tensor) or name in self._parameters or name in self._buffers:
+            self._epoch[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        self._epoch[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        self._epoch[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        self._epoch[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
 
 
 class NVPrecond(torch.nn.Module):
@@ -90,11 +113,17 @@ class NVPrecond(torch.nn.Module):
         self.dual_source = dual_source
 
         # parameters / buffers under the reference's names, with the reference's initialisation
+        self._tree_epoch = [0]
         for key, shape in state_dict_shapes(self.cfg).items():
             *path, leaf = key.split(".")
             node = self
             for name in path:
-                node = node.child(name) if isinstance(node, _Node) else _Node.child(node, name)
+                if isinstance(node, _Node):
+                    node = node.child(name)
+                else:
+                    if name not in node._modules:
+                        node.add_module(name, _Node(self._tree_epoch))
+                    node = node._modules[name]
             if leaf == "freqs":
                 node.register_buffer(leaf, 2 * np.pi * torch.randn(shape))
             elif leaf == "phases":
@@ -136,12 +165,14 @@ class NVPrecond(torch.nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _fingerprint(self):
-        """Changes whenever the weights may have: an epoch bumped by load_state_dict / _apply, plus the autograd version counters
-        of the ~400 tensors (in-place edits), summed over a cached flat list instead of a walk of the module tree per call."""
-        if self._tensors is None:
-            self._tensors = list(self.parameters()) + list(self.buffers())
-        ts = self._tensors
-        return (self._weights_epoch, sum(t._version for t in ts), ts[0].data_ptr() if ts else 0)
+        """Changes whenever the weights may have: an epoch bumped by load_state_dict / _apply, the tree epoch bumped by any tensor
+        assignment / registration / deletion in the parameter tree (_Node), plus the autograd version counters of the ~400 tensors
+        (in-place edits), summed over a flat list that is rebuilt only when one of the epochs moved."""
+        epoch = (self._weights_epoch, self._tree_epoch[0])
+        if self._tensors is None or self._tensors[0] != epoch:
+            self._tensors = (epoch, list(self.parameters()) + list(self.buffers()))
+        ts = self._tensors[1]
+        return (epoch, sum(t._version for t in ts), ts[0].data_ptr() if ts else 0)
 
     def _prepare(self, device):
         fp = self._fingerprint()
@@ -220,8 +251,8 @@ class NVPrecond(torch.nn.Module):
                 put("x", dst, (rows, cfg.img_channels, R, R))
             if "cond" in prog.io:
                 cond = conditioning_image.to(torch.float32)
-                if cfg.noisy_sr:
-                    cond = cond + cfg.noisy_sr * torch.randn_like(cond)                         # :658
+                if self.noisy_sr:                    # read per call like the reference's self.noisy_sr (:658): callers may set it
+                    cond = cond + self.noisy_sr * torch.randn_like(cond)
                 put("cond", cond, (B, cfg.img_channels, R, R))
             if mode == "inject":
                 # copied on every call, like the reference's deepcopy (:665): a cache keyed on addresses goes stale when the

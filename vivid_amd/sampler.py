@@ -9,7 +9,8 @@ feature reuse for ``no_time_enc`` nets (:52-53).  The per-step arithmetic runs i
 one HIP kernel (``vh_sampler_step``); the denoiser calls go to whatever ``net`` /
 ``gnet`` are (normally :class:`vivid_amd.NVPrecond`).
 
-``StackedRandomGenerator`` mirrors ``generate_images.py:120-134``.
+``StackedRandomGenerator`` keeps the contract of ``generate_images.py:120-134`` (per-seed streams); its ``randint`` has no
+caller on this path and is not provided.
 """
 from __future__ import annotations
 
@@ -94,19 +95,29 @@ def edm_sampler(
 
 
 class StackedRandomGenerator:
-    """One generator per seed, so a sample's noise depends on its seed only, not on its batch or
-    rank (generate_images.py:120-134)."""
+    """Per-seed random streams stacked along the batch axis: row i of every draw comes from a generator seeded with
+    ``seeds[i] % 2**32`` and from nothing else, so a sample's noise does not depend on which batch or rank it lands in - the
+    contract of the reference's class of the same name (generate_images.py:120-134), which the driver and ``edm_sampler``'s
+    ``randn_like`` hook rely on."""
 
     def __init__(self, device, seeds):
-        self.generators = [torch.Generator(device).manual_seed(int(seed) % (1 << 32)) for seed in seeds]
+        self.device = torch.device(device)
+        self.streams = []
+        for seed in seeds:
+            g = torch.Generator(self.device)
+            g.manual_seed(int(seed) % (1 << 32))
+            self.streams.append(g)
+
+    def _stacked(self, draw, size):
+        """One draw of shape size[1:] per stream, stacked; size[0] must be the number of seeds."""
+        size = tuple(size)
+        if size[0] != len(self.streams):
+            raise ValueError(f"leading dimension {size[0]} != number of seeds {len(self.streams)}")
+        rows = [draw(size[1:], g) for g in self.streams]
+        return torch.stack(rows) if rows else torch.empty((0,) + size[1:], device=self.device)
 
     def randn(self, size, **kwargs):
-        assert size[0] == len(self.generators)
-        return torch.stack([torch.randn(size[1:], generator=gen, **kwargs) for gen in self.generators])
+        return self._stacked(lambda shape, g: torch.randn(shape, generator=g, **kwargs), size)
 
     def randn_like(self, input):
         return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
-
-    def randint(self, *args, size, **kwargs):
-        assert size[0] == len(self.generators)
-        return torch.stack([torch.randint(*args, size=size[1:], generator=gen, **kwargs) for gen in self.generators])
