@@ -20,8 +20,10 @@ Prints ONE JSON line on rank 0.  Besides BASELINE's metric it carries, at N = 1:
   roofline          dominant kernel family of the timed region (HIP events on the launch stream), against both peak bases
   parity            HIP vs the CPU oracle on one batch-1 guided evaluation of the SAME networks (the gate BASELINE.md 4 promises)
   cpu_baseline      that oracle evaluation timed on the host cores (after one warm-up call)
-  other_workloads   short runs of the same step in exact-fp32 mode and of BASELINE configs[3] (SR net built at 1024^2, B=4) and
-                    configs[4] (base + depth-warp features at 256^2, B=16); `--no-extras` skips them
+  other_workloads   short runs of the same step in exact-fp32 mode, of BASELINE configs[3] (SR net built at 1024^2, B=4) and
+                    configs[4] (base + depth-warp features at 256^2, B=16), and of the reference's own cascade stages (base@64 +
+                    guidance at batch 32 and batch 1, SR@256 at batch 32) with `wall_over_kernel`; each bf16x3 one carries
+                    `parity.batchN_vs_batch1`; `--no-extras` skips them
 """
 import argparse
 import gc
@@ -46,6 +48,11 @@ WORKLOADS = {
     "c4": ("sr", 1024, 4, False, "vivid-sr arch built @1024x1024 (256->1024), batch 4, no guidance (the SR stage has none), noisy_sr 0.25"),
     "c5": ("warp", 256, 16, False, "vivid-base + depth-warp Fourier features @256x256, batch 16, one net evaluation (no guidance net)"),
     "base64": ("base", 64, 16, True, "vivid-base @64x64 (the reference's own base stage), batch 16, CFG 1.5"),
+    # the reference's real presets (train_nvs.py:28-30, training/training_loop.py:236): base stage at 64^2, SR stage 64 -> 256,
+    # at generate_images.py's default max_batch_size of 32
+    "ref_base64_b32": ("base", 64, 32, True, "reference-true base stage: vivid-base + vivid-uncond @64x64, batch 32, CFG 1.5"),
+    "ref_sr256_b32": ("sr", 256, 32, False, "reference-true SR stage: vivid-sr @256x256 (64->256), batch 32, no guidance, noisy_sr 0.25"),
+    "ref_base64_b1": ("base", 64, 1, True, "reference-true base stage at batch 1 (latency case): vivid-base + vivid-uncond @64x64, CFG 1.5"),
     "tiny": ("base", 64, 1, True, "vivid-base @64x64, batch 1, CFG 1.5 (plumbing)"),
 }
 
@@ -182,8 +189,35 @@ def roofline_of(dom, fam, kern, ms_per_step, precision):
     return out
 
 
-def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True, batch=None, keep_nets=False):
-    """Times `steps` steps of one workload after `warmup` untimed ones; returns (result dict, (net, gnet) or None)."""
+def batch_vs_batch1(net, gnet, src, x, tt, geo, cond, picks):
+    """The timed configuration against its own batch-1 evaluations (which tests/test_hip_timed_configs.py pin to the CPU oracle):
+    one evaluation at the full batch, then the samples `picks` alone.  The launcher picks kernels by grid size (tile shapes, K order,
+    split-K), so this is what ties the kernels that are TIMED to the parity chain.  Returns the largest rel-L2 seen."""
+    saved = [(n, n.noisy_sr) for n in (net, gnet) if n is not None]
+    for n, _ in saved:
+        n.noisy_sr = 0.0                      # the SR net draws randn inside forward (training/models.py:658): off, so both batches see one input
+    try:
+        worst = 0.0
+        for n in (net, gnet):
+            if n is None:
+                continue
+            g = geo if n is net else None
+            full = n(src, x, tt, g, cond)
+            for i in picks:
+                one = n(src[2 * i:2 * i + 2], x[2 * i:2 * i + 2], tt[2 * i:2 * i + 2], None if g is None else g[2 * i:2 * i + 2],
+                        None if cond is None else cond[i:i + 1])
+                worst = max(worst, rel_l2(full[i:i + 1], one))
+    finally:
+        for n, v in saved:
+            n.noisy_sr = v
+    return worst
+
+
+def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True, batch=None, keep_nets=False, parity_picks=None,
+                 wall_probe=False):
+    """Times `steps` steps of one workload after `warmup` untimed ones; returns (result dict, (net, gnet) or None).
+    parity_picks: sample indices for batch_vs_batch1 (after the timed region).  wall_probe: additionally time `steps` steps with
+    per-launch events OFF (`wall_ms_unprofiled`) - the latency-bound workloads are judged on wall time over summed kernel time."""
     import vivid_amd  # noqa: F401
     from vivid_amd.sampler import _context, _step
     kind, R, B, guided, desc = WORKLOADS[name]
@@ -240,7 +274,20 @@ def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True,
                 for kk in a:
                     a[kk] += v[kk]
             c.profile_enable(False)
-    res = dict(name=name, desc=desc, R=R, B=B, guided=guided, precision=precision, steps=steps, warmup=warmup, elapsed=elapsed,
+    extra = {}
+    if wall_probe:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + steps + i)
+        torch.cuda.synchronize()
+        extra["wall_ms_unprofiled"] = 1000.0 * (time.perf_counter() - t1) / steps
+        extra["hipgraph"] = bool(getattr(list(net._engine.programs.values())[0].plan, "graph_captured", False))
+    if parity_picks:
+        tt = torch.full((2 * B,), 5.0, device=dev)
+        picks = [i for i in parity_picks if i < B]
+        extra["batch_vs_batch1"] = dict(batch=B, samples=picks, rel_l2_max=batch_vs_batch1(net, gnet, src, noise * 5.0, tt, geo, cond, picks))
+    res = dict(name=name, desc=desc, R=R, B=B, guided=guided, precision=precision, steps=steps, warmup=warmup, elapsed=elapsed, extra=extra,
                ms_per_step=1000.0 * elapsed / steps, fam=fam, finite=bool(torch.isfinite(state["x"]).all().item()),
                params={"net": sum(p.numel() for p in net.parameters()), **({"gnet": sum(p.numel() for p in gnet.parameters())} if gnet is not None else {})})
     if keep_nets:
@@ -263,6 +310,20 @@ def summarise(res, world):
         out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "share_of_step")}
         out["kernels"] = {k: {"ms_per_step": v["ms_per_step"], "tflops": v["tflops"], "gbs": v["gbs"]} for k, v in kern.items()}
         out["whole_step_tflops"] = sum(v["flops"] for v in res["fam"].values()) / res["elapsed"] / 1e12
+        ksum = sum(v["ms"] for v in res["fam"].values()) / res["steps"]
+        out["kernel_ms_per_step"] = ksum
+        out["launches_per_step"] = sum(v["launches"] for v in res["fam"].values()) / res["steps"]
+        if "wall_ms_unprofiled" in res["extra"]:
+            # wall time of a step with per-launch events off over the summed kernel durations measured with them on: 1.0 = the GPU
+            # never waits for the host or for a dependent launch to start
+            out["wall_ms_per_step_unprofiled"] = res["extra"]["wall_ms_unprofiled"]
+            out["wall_over_kernel"] = res["extra"]["wall_ms_unprofiled"] / ksum
+            out["hipgraph_replay"] = res["extra"].get("hipgraph")
+    if "batch_vs_batch1" in res["extra"]:
+        b = res["extra"]["batch_vs_batch1"]
+        out["parity"] = {f"batch{b['batch']}_vs_batch1": b["rel_l2_max"], "samples": b["samples"], "tolerance": 2e-5,
+                         "pass": bool(b["rel_l2_max"] < 2e-5),
+                         "note": "HIP at the timed batch vs the same nets at batch 1 (pinned to the CPU oracle by tests/test_hip_timed_configs.py)"}
     return out
 
 
@@ -354,6 +415,20 @@ def main():
         out["parity"] = {"rel_l2_D": rel_l2(D.cpu(), cb["D"]), "rel_l2_guided": rel_l2(guided.cpu(), cb["guided"]), "tolerance": 1e-3,
                          "against": "oracle/vivid_ref.py (CPU, fp32) on the same weights and inputs, batch 1, sigma 5, guidance 1.5",
                          "pass": bool(rel_l2(guided.cpu(), cb["guided"]) < 1e-3)}
+        # the TIMED configuration: one evaluation at the timed batch whose sample 0 is the oracle's input; samples 0 / middle / last
+        # against their own batch-1 evaluations (different tile shapes, K order and split-K at the two grid sizes)
+        srcB, noiseB, geoB, _ = make_inputs(R, B, 100, dev)
+        xB = noiseB * 5.0
+        srcB[:2], xB[:2], geoB[:2] = src, x, geo
+        tB = torch.full((2 * B,), 5.0, device=dev)
+        DB, GB = net(srcB, xB, tB, geoB), gnet(srcB, xB, tB)
+        out["parity"][f"batch{B}_sample0_vs_oracle"] = rel_l2(GB[:1].lerp(DB[:1], 1.5).cpu(), cb["guided"])
+        out["parity"][f"batch{B}_vs_batch1"] = max(rel_l2(DB[:1], D), rel_l2(GB[:1], Dg),
+                                                   batch_vs_batch1(net, gnet, srcB, xB, tB, geoB, None, [B // 2 - 1, B - 1] if B > 2 else []))
+        out["parity"]["batch_samples"] = sorted({0, B // 2 - 1, B - 1}) if B > 2 else [0]
+        out["parity"]["pass"] = bool(out["parity"]["pass"] and out["parity"][f"batch{B}_sample0_vs_oracle"] < 1e-3
+                                     and out["parity"][f"batch{B}_vs_batch1"] < 2e-5)
+        del srcB, noiseB, geoB, xB, DB, GB
         out["cpu_baseline"] = {"value": 1.0 / (B * cb["seconds_b1"]), "unit": out["unit"], "cores": cb["cores"], "kind": "port",
                                "sample": f"one guided evaluation (net + uncond gnet) of the same {R}x{R} networks at batch 1 on the CPU oracle "
                                          f"took {cb['seconds_b1']:.2f} s after one untimed warm-up call ({cb['seconds_b1_cold']:.2f} s cold); "
@@ -364,9 +439,15 @@ def main():
 
     if world == 1 and headline and not args.no_extras and rank == 0:
         extras = {}
-        for key, (wl, prec, k, w) in {"c2_fp32": ("c2", "fp32", 2, 1), "c4_sr1024_b4": ("c4", "bf16x3", 3, 1),
-                                      "c5_warp256_b16": ("c5", "bf16x3", 3, 1)}.items():
-            r2, _ = run_workload(wl, prec, k, w, dev, rank, world, profile=not args.no_profile)
+        for key, (wl, prec, k, w, picks, probe) in {
+                "c2_fp32": ("c2", "fp32", 2, 1, None, False),
+                "c4_sr1024_b4": ("c4", "bf16x3", 3, 1, (0, 3), False),
+                "c5_warp256_b16": ("c5", "bf16x3", 3, 1, (0, 7, 15), False),
+                # the reference's own presets: latency-sensitive shapes, judged on wall time over summed kernel time as well
+                "ref_base64_b32": ("ref_base64_b32", "bf16x3", 10, 3, (0, 15, 31), True),
+                "ref_sr256_b32": ("ref_sr256_b32", "bf16x3", 5, 2, (0, 31), True),
+                "ref_base64_b1": ("ref_base64_b1", "bf16x3", 20, 5, None, True)}.items():
+            r2, _ = run_workload(wl, prec, k, w, dev, rank, world, profile=not args.no_profile, parity_picks=picks, wall_probe=probe)
             extras[key] = summarise(r2, world)
         out["other_workloads"] = extras
     if rank == 0:

@@ -122,6 +122,13 @@ def _rand_conv_shapes():
         out.append((rows, h, w, cin, cout, taps, epi, up))
     out.append((2, 128, 128, 64, 128, 9, 2, 0))        # large enough for the chunk-major K order? (no: < 150 MB) - tall tiles
     out.append((1, 64, 64, 512, 256, 9, 0, 0))         # wide tiles, 16 tiles -> split-K 8
+    # the low-resolution levels of the reference's own base@64 preset at batch 1: a quarter-filled 256-row tile, 10-16 K slices of
+    # 4+ K-tiles, blocks wholly outside the output skipped
+    out.append((1, 8, 8, 512, 512, 9, 2, 0))
+    out.append((2, 8, 8, 1024, 512, 9, 1, 0))
+    out.append((1, 16, 16, 384, 384, 9, 2, 0))
+    out.append((2, 8, 8, 512, 512, 1, 2, 0))
+    out.append((1, 16, 16, 768, 384, 1, 0, 0))
     return out
 
 

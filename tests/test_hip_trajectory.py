@@ -9,9 +9,9 @@ call.  This file runs the reference-true cascade at its real widths:
   stage 2  vivid-sr @256 (train_nvs.py:30; noisy_sr = 0 so that both sides see the same conditioning), 16 steps = 31 calls, on the
            stage-1 output resized as generate_images.py:322 does (net = gnet = sr_model, guidance 1, :324-326).
 
-Gates: rel-L2 of the final latents <= 1e-3 (north_star's tolerance), decoded uint8 images within +-1 LSB.  `trajectory_errors`
-also returns the error after every denoiser call (the HIP sampler's x against the oracle's x at the same call), which
-tools/trajectory_report.py prints for DESIGN.md 4.
+Gates: rel-L2 of the final latents <= 1e-3 (north_star's tolerance), decoded uint8 images within +-1 LSB.  `base_stage` /
+`sr_stage` also return the error after every denoiser call (the HIP sampler's x against the oracle's x at the same call), which
+tools/trajectory_report.py prints for DESIGN.md 4.  The two stages are two tests (about 1.5 min of oracle time each).
 """
 import pytest
 import torch
@@ -57,55 +57,101 @@ def base_stage_inputs(seed=31):
     return src, geo, noise
 
 
-def trajectory_errors(precisions=("bf16x3", "fp32"), num_steps=32, sr_steps=16):
-    """Returns {precision: dict(base_final, base_per_call, sr_final, sr_per_call, u8_base, u8_sr)} (errors are rel-L2 vs the oracle)."""
+class _Threads:
+    """The GPU box gives a job 16 cores but torch sees all 128: the oracle's small layers (8x8 ... 64x64) crawl when 128 threads
+    fight over them.  Cap the intra-op pool for the oracle legs."""
+
+    def __init__(self, n=16):
+        self.n = n
+
+    def __enter__(self):
+        self.saved = torch.get_num_threads()
+        torch.set_num_threads(min(self.saved, self.n))
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.saved)
+
+
+def _cascade_nets():
     import vivid_amd
-    from vivid_amd.generate import resize
     bcfg, ucfg = vivid_amd.vivid_base(64), vivid_amd.vivid_uncond(64)
     scfg = vivid_amd.vivid_sr(256, noisy_sr=0.0)
-    bsd, usd, ssd = (vivid_amd.synth_state_dict(c, seed=s) for c, s in ((bcfg, 0), (ucfg, 1), (scfg, 2)))
+    sds = [vivid_amd.synth_state_dict(c, seed=s) for c, s in ((bcfg, 0), (ucfg, 1), (scfg, 2))]
+    return (bcfg, ucfg, scfg), sds
+
+
+def base_stage(precisions=("bf16x3", "fp32"), num_steps=32, log=None):
+    """Stage 1 on both sides.  Returns dict(oracle=latents, <precision>=dict(latents (cuda), final, per_call, sigmas, u8))."""
+    import vivid_amd
+    (bcfg, ucfg, _), (bsd, usd, _) = _cascade_nets()
     src, geo, noise = base_stage_inputs()
-    g = torch.Generator().manual_seed(32)
-    sr_src = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
-    sr_noise = R.StackedRandomGenerator("cpu", [16]).randn([1, 3, 256, 256]).repeat_interleave(2, dim=0)
-
-    # oracle cascade
-    obase, ounc, osr = R.OracleNet(_ocfg(bcfg), bsd), R.OracleNet(_ocfg(ucfg), usd), R.OracleNet(_ocfg(scfg), ssd)
-    tr_b, tr_s = [], []
-    lat = R.edm_sampler(obase, src, noise, labels=geo, gnet=ounc, num_steps=num_steps, guidance=1.5, trace=tr_b)
-    low = torch.nn.functional.interpolate(lat, size=(256, 256), mode="bilinear", align_corners=False, antialias=True)
-    sr_lat = R.edm_sampler(osr, sr_src, sr_noise, labels=geo, gnet=osr, conditioning_image=low, num_steps=sr_steps, trace=tr_s)
-    assert len(tr_b) == 2 * num_steps - 1 and len(tr_s) == 2 * sr_steps - 1
-
-    out = {}
+    obase, ounc = R.OracleNet(_ocfg(bcfg), bsd), R.OracleNet(_ocfg(ucfg), usd)
+    tr = []
+    with _Threads():
+        lat = R.edm_sampler(obase, src, noise, labels=geo, gnet=ounc, num_steps=num_steps, guidance=1.5, trace=tr)
+    assert len(tr) == 2 * num_steps - 1
+    out = dict(oracle=lat)
     for prec in precisions:
-        net, gnet, sr = _hip(bcfg, bsd, prec), _hip(ucfg, usd, prec), _hip(scfg, ssd, prec)
+        net, gnet = _hip(bcfg, bsd, prec), _hip(ucfg, usd, prec)
         rec = _Recorder(net)
         hlat = vivid_amd.edm_sampler(rec, src.cuda(), noise.cuda(), labels=geo.cuda(), gnet=gnet, num_steps=num_steps, guidance=1.5)
-        hlow = resize(hlat, 256)
-        rec_s = _Recorder(sr)
-        hsr = vivid_amd.edm_sampler(rec_s, sr_src.cuda(), sr_noise.cuda(), labels=geo.cuda(), gnet=sr, conditioning_image=hlow,
-                                    num_steps=sr_steps)
-        assert len(rec.xs) == len(tr_b) and len(rec_s.xs) == len(tr_s)
-        out[prec] = dict(
-            base_final=rel_l2(hlat.cpu(), lat), sr_final=rel_l2(hsr.cpu(), sr_lat),
-            base_per_call=[rel_l2(h.cpu(), o[1][::2]) for h, o in zip(rec.xs, tr_b)],
-            sr_per_call=[rel_l2(h.cpu(), o[1][::2]) for h, o in zip(rec_s.xs, tr_s)],
-            sigmas=[o[0] for o in tr_b],
-            u8_base=int((R.decode_latents(hlat.cpu()).int() - R.decode_latents(lat).int()).abs().max()),
-            u8_sr=int((R.decode_latents(hsr.cpu()).int() - R.decode_latents(sr_lat).int()).abs().max()),
-            u8_sr_frac=float(((R.decode_latents(hsr.cpu()).int() - R.decode_latents(sr_lat).int()).abs() > 0).float().mean()))
-        del net, gnet, sr, rec, rec_s
+        assert len(rec.xs) == len(tr)
+        out[prec] = dict(latents=hlat, final=rel_l2(hlat.cpu(), lat), sigmas=[o[0] for o in tr],
+                         per_call=[rel_l2(h.cpu(), o[1][::2]) for h, o in zip(rec.xs, tr)],
+                         u8=int((R.decode_latents(hlat.cpu()).int() - R.decode_latents(lat).int()).abs().max()))
+        del net, gnet, rec
         torch.cuda.empty_cache()
     return out
 
 
-def test_full_length_guided_cascade_vs_oracle():
-    res = trajectory_errors()
+def sr_stage(base, precisions=("bf16x3", "fp32"), sr_steps=16):
+    """Stage 2 on the stage-1 outputs of each side (generate_images.py:310-327: resize the latents, net = gnet = sr_model)."""
+    import vivid_amd
+    from vivid_amd.generate import resize
+    (_, _, scfg), (_, _, ssd) = _cascade_nets()
+    _, geo, _ = base_stage_inputs()
+    g = torch.Generator().manual_seed(32)
+    sr_src = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    sr_noise = R.StackedRandomGenerator("cpu", [16]).randn([1, 3, 256, 256]).repeat_interleave(2, dim=0)
+    osr = R.OracleNet(_ocfg(scfg), ssd)
+    tr = []
+    with _Threads():
+        low = torch.nn.functional.interpolate(base["oracle"], size=(256, 256), mode="bilinear", align_corners=False, antialias=True)
+        sr_lat = R.edm_sampler(osr, sr_src, sr_noise, labels=geo, gnet=osr, conditioning_image=low, num_steps=sr_steps, trace=tr)
+    assert len(tr) == 2 * sr_steps - 1
+    out = {}
+    for prec in precisions:
+        sr = _hip(scfg, ssd, prec)
+        rec = _Recorder(sr)
+        hsr = vivid_amd.edm_sampler(rec, sr_src.cuda(), sr_noise.cuda(), labels=geo.cuda(), gnet=sr,
+                                    conditioning_image=resize(base[prec]["latents"], 256), num_steps=sr_steps)
+        assert len(rec.xs) == len(tr)
+        diff = (R.decode_latents(hsr.cpu()).int() - R.decode_latents(sr_lat).int()).abs()
+        out[prec] = dict(final=rel_l2(hsr.cpu(), sr_lat), per_call=[rel_l2(h.cpu(), o[1][::2]) for h, o in zip(rec.xs, tr)],
+                         u8=int(diff.max()), u8_frac=float((diff > 0).float().mean()))
+        del sr, rec
+        torch.cuda.empty_cache()
+    return out
+
+
+@pytest.fixture(scope="module")
+def base():
+    return base_stage()
+
+
+def test_full_length_guided_base_stage_vs_oracle(base):
+    """63 guided evaluations of vivid-base@64 + vivid-uncond@64 (oracle leg: ~1.5 min of host time)."""
+    for prec in ("bf16x3", "fp32"):
+        r = base[prec]
+        msg = f"{prec}: final {r['final']:.2e}, max over the 63 calls {max(r['per_call']):.2e}, uint8 max diff {r['u8']}"
+        assert r["final"] < 1e-3 and max(r["per_call"]) < 1e-3, msg
+        assert r["u8"] <= 1, msg
+
+
+def test_full_length_sr_stage_on_that_output_vs_oracle(base):
+    """31 evaluations of vivid-sr@256 on the resized stage-1 latents (oracle leg: ~1.5 min of host time)."""
+    res = sr_stage(base)
     for prec, r in res.items():
-        msg = f"{prec}: base {r['base_final']:.2e} (max over calls {max(r['base_per_call']):.2e}), sr {r['sr_final']:.2e}"
-        print(msg)
-        assert r["base_final"] < 1e-3, msg
-        assert r["sr_final"] < 1e-3, msg
-        assert max(r["base_per_call"]) < 1e-3 and max(r["sr_per_call"]) < 1e-3, msg
-        assert r["u8_base"] <= 1 and r["u8_sr"] <= 1, (prec, r["u8_base"], r["u8_sr"])
+        msg = f"{prec}: final {r['final']:.2e}, max over the 31 calls {max(r['per_call']):.2e}, uint8 max diff {r['u8']} ({100 * r['u8_frac']:.3f} % of pixels)"
+        assert r["final"] < 1e-3 and max(r["per_call"]) < 1e-3, msg
+        assert r["u8"] <= 1, msg

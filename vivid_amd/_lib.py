@@ -287,8 +287,11 @@ class Plan:
     def num_ops(self) -> int:
         return self.ctx._L.vh_plan_num_ops(self.handle)
 
+    graph_captured = False
+
     def capture_graph(self):
         check(self.ctx._L.vh_plan_capture_graph(self.ctx.handle, self.handle), "vh_plan_capture_graph")
+        self.graph_captured = True
 
     def run(self):
         check(self.ctx._L.vh_plan_run(self.ctx.handle, self.handle), "vh_plan_run")

@@ -483,6 +483,7 @@ __global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
                 const EpiAux cur = ring[b % PD];
                 if (b + PD < NB) ring[b % PD] = prefetch(b + PD);
                 const int r0 = m0 + (wm * MI + mi) * 32, c0 = n0 + (wn * NI + ni) * 32;
+                if (r0 >= e.M || c0 >= e.cout) continue;     // wholly outside (a 64-pixel level in a 256-row tile): nothing to walk
                 if (inside(b))
                     conv_epilogue_block_fast<EPI>(e, acc16[2 * mi][2 * ni], acc16[2 * mi][2 * ni + 1], acc16[2 * mi + 1][2 * ni],
                                                   acc16[2 * mi + 1][2 * ni + 1], r0, c0, patch, l, cur);
@@ -582,7 +583,9 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     if (a.scratch && MT * NT < 256 && KTall >= 16 && a.epi != VH_EPI_QKV) {
         // pick the slice count that minimises (rounds of 256 workgroups) x (K per slice), with a small charge per slice for the
         // reducer's extra traffic: e.g. 128 tiles -> 2 slices (one full round), not 3 (a full and a half-empty round)
-        const int smax = (int)std::min<long long>(8, KTall / 8);
+            // (up to 16 slices of >= 4 K-tiles when the tiles alone would occupy an eighth of the chip or less: the 8x8 / 16x16 levels of the
+        //  reference's 64x64 preset at batch 1, where a launch is ~25 us of fixed costs and the K loop is all that can shrink)
+        const int smax = MT * NT <= 32 ? (int)std::min<long long>(16, KTall / 4) : (int)std::min<long long>(8, KTall / 8);
         double best = 1e30;
         for (int ks = 1; ks <= smax; ++ks) {
             if ((size_t)ks * (size_t)M * a.cout > a.scratch_floats) break;
