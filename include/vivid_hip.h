@@ -54,7 +54,8 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * "conv_korder": -1 (default) K order of the 3x3 bf16x3 convolutions by input size / vh_conv_args.korder, 0 tap-major, 1 chunk-major;
  * "conv_stagger": -1 (default) vh_conv_args.stagger decides, 0 never, 1 always;
  * "attn_pipe": 1 (default) software-pipelined bf16x3 attention kernels for long sequences, 0 the plain ones;
- * "attn_nomax": 1 (default) bounded-logit attention keeps no running maximum, 0 keeps it.
+ * "attn_nomax": 1 (default) bounded-logit attention keeps no running maximum, 0 keeps it;
+ * "conv_slim2": -1 (default) Cout <= 64 layers at large M take the 256x64 tile (two workgroups per CU), 0 the 512x64 one.
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);
 
@@ -170,11 +171,12 @@ typedef struct {
                                               different order: results agree to fp32 rounding, not bit for bit. */
     int tile;                              /* VH_CONV_GLDS256: workgroup tile, VH_TILE_AUTO (by shape and grid size) or a forced shape
                                               (pixels x output channels): VH_TILE_256x128, VH_TILE_256x256 (needs cout % 256 == 0),
-                                              VH_TILE_512x128, VH_TILE_512x64 (needs cout <= 64).  A forced shape disables split-K unless
+                                              VH_TILE_512x128, VH_TILE_512x64 and VH_TILE_256x64 (need cout <= 64; the latter runs two
+                                              workgroups per CU).  A forced shape disables split-K unless
                                               the grid is small; every shape computes the same sums in the same order. */
 } vh_conv_args;
 enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
-enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4 };
+enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5 };
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
 
 /* ---- K6 (+K9): pixel norm with optional 2x2 mean pooling ------------------

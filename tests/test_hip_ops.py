@@ -170,7 +170,7 @@ def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("korder", [1, 2])                  # VH_KORDER_TAP, VH_KORDER_CHUNK
-@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64
+@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU)
 def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
     """Every workgroup tile of conv_x3_glds with both K orders and every epilogue, forced through vh_conv_args.tile / .korder on a
     small ragged problem, against the oracle's mp_conv (the wide tile with chunk-major K is what the headline 128x128 layers run;

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from vivid_amd import _lib as L  # noqa: E402
 
 
-KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1}
+KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1}
 
 
 def load(suffix):
@@ -76,6 +76,7 @@ def main():
         k_pad, M = taps * cin, rows * h * w
         flops = 2.0 * M * cout * cin * taps
         res = torch.randn(M, cout, generator=g).cuda() if epi == 2 else None
+        cvec = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda() if epi == 1 else None
         for name, lib, knobs in parse_variants():
             ctx = load(lib)
             s8 = torch.empty(M * cin, device="cuda")
@@ -90,7 +91,7 @@ def main():
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
                            scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if s8mode != 1 else None, out_s8=o8.data_ptr() if o8 is not None else None,
                            out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,
-                           cvec=None, cvec_ld=0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
+                           cvec=cvec.data_ptr() if cvec is not None else None, cvec_ld=cout if cvec is not None else 0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
                            korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0))
             runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, o8 if s8mode == 1 else out)))
 

@@ -14,6 +14,7 @@ ap.add_argument("--uncond", action="store_true")
 ap.add_argument("--sr", action="store_true")
 ap.add_argument("--warp", action="store_true")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--top", type=int, default=45, help="lines to print (0 = all)")
 a = ap.parse_args()
 if a.sr:
     cfg = vivid_amd.vivid_sr(a.res)
@@ -51,5 +52,5 @@ for i, d in enumerate(prog.oplog):
     e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
 tot = sum(e[1] for e in agg.values())
 print(f"total {tot:.1f} ms over {n} launches")
-for d, (c, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+for d, (c, ms, fl, by) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:(a.top or None)]:
     print(f"{ms:9.2f} ms {100*ms/tot:5.1f}%  x{c:3d}  {fl/ms/1e9 if ms else 0:7.1f} TF/s {by/ms/1e6 if ms else 0:8.1f} GB/s  {d}")

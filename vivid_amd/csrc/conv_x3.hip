@@ -61,8 +61,12 @@ __device__ __forceinline__ void wait_dma() {
 // CHUNK = true: channel-chunk-major K order (9 taps only).  A template parameter rather than a run-time flag so that each
 // instantiation keeps only ITS per-slot state in registers (pixel coordinates for tap-major, centre pointer + tap mask for
 // chunk-major): with both live the 512x128 tile needed 256 VGPRs + 40 bytes of scratch per lane.
-template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16, bool CHUNK>
-__global__ __launch_bounds__(512, 2) void conv_x3_glds(const ConvK a) {
+// OCC = waves per SIMD the register budget is set for: 2 (<= 256 VGPRs, one workgroup per CU) for the big tiles; 4 (<= 128 VGPRs) for the
+// 256x64 tile, whose 80 KB of LDS fit twice per CU - two independent workgroups, so that one's prologue / epilogue / turnaround runs
+// under the other's K loop (the full-resolution 64-channel layers of the SR net have K loops of 18 K-tiles: most of a 512x64 tile's time
+// was outside its loop).
+template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16, bool CHUNK, int OCC = 2>
+__global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
     static_assert(!CHUNK || TAPS == 9, "chunk-major order exists for 3x3 convolutions only");
     static_assert(WAVES_M * WAVES_N == 8, "8 waves");
     constexpr int BM = WAVES_M * MI * 32, BN = WAVES_N * NI * 32;
@@ -537,15 +541,17 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long lo
 }  // namespace
 
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_>), dim3(grid), dim3(512), 0, s, k)
+#define VH_LAUNCH_OCC4(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_, 4>), dim3(grid), dim3(512), 0, s, k)
 #define VH_LAUNCH_CFG(T, CH_)                                  \
     do {                                                       \
-        if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, CH_);           \
+        if (cfg == 5) VH_LAUNCH_OCC4(T, 8, 1, 1, 2, CH_);      \
+        else if (cfg == 3) VH_LAUNCH(T, 8, 1, 2, 2, CH_);      \
         else if (cfg == 2) VH_LAUNCH(T, 4, 2, 4, 2, CH_);      \
         else if (cfg == 1) VH_LAUNCH(T, 2, 4, 4, 2, CH_);      \
         else VH_LAUNCH(T, 4, 2, 2, 2, CH_);                    \
     } while (0)
 
-// cfg: 0 = 256x128 tile, 1 = 256x256, 2 = 512x128, 3 = 512x64
+// cfg: 0 = 256x128 tile, 1 = 256x256, 2 = 512x128, 3 = 512x64, 5 = 256x64 (two workgroups per CU)
 #if VH_CONV_TU != 9
 void vh_conv_x3_launch_1tap(const vhconv::ConvK& k, int cfg, unsigned grid, hipStream_t s) { VH_LAUNCH_CFG(1, false); }
 #else
@@ -569,10 +575,15 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     bool slim = a.cout <= 64 && (M + 511) / 512 >= 512;
     if (a.tile != VH_TILE_AUTO) {                          // caller's choice (tests sweep every shape on small problems)
         if (a.tile == VH_TILE_256x256 && a.cout % 256) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_256x256 needs cout %% 256 == 0 (got %d)", a.cout);
-        if (a.tile == VH_TILE_512x64 && a.cout > 64) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_512x64 needs cout <= 64 (got %d)", a.cout);
-        wide = a.tile == VH_TILE_256x256; tall = a.tile == VH_TILE_512x128; slim = a.tile == VH_TILE_512x64;
+        if ((a.tile == VH_TILE_512x64 || a.tile == VH_TILE_256x64) && a.cout > 64) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_512x64 / VH_TILE_256x64 need cout <= 64 (got %d)", a.cout);
+        wide = a.tile == VH_TILE_256x256; tall = a.tile == VH_TILE_512x128; slim = a.tile == VH_TILE_512x64 || a.tile == VH_TILE_256x64;
     }
-    const int BN = wide ? 256 : slim ? 64 : 128, BMt = (tall || slim) ? 512 : 256;
+    // 256x64 with two workgroups per CU instead of 512x64 with one: +7..15 % on every Cout <= 64 layer measured (3x3 with 18-54 K-tiles, 1x1;
+    // fp32 or S8 output; profiles/r03_ab_conv_slim2.txt) - one workgroup's prologue, epilogue and turnaround run under the other's K loop.
+    // Knob "conv_slim2": -1 (default) always, 0 never (the 512x64 tile stays reachable for A/B and through vh_conv_args.tile).
+    const int slim2_knob = vh_knob(VH_KNOB_CONV_SLIM2);
+    const bool slim2 = slim && (a.tile == VH_TILE_256x64 || (a.tile == VH_TILE_AUTO && slim2_knob != 0));
+    const int BN = wide ? 256 : slim ? 64 : 128, BMt = slim2 ? 256 : (tall || slim) ? 512 : 256;
     const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
     k.NT = (int)NT;
@@ -583,7 +594,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     if (a.scratch && MT * NT < 256 && KTall >= 16 && a.epi != VH_EPI_QKV) {
         // pick the slice count that minimises (rounds of 256 workgroups) x (K per slice), with a small charge per slice for the
         // reducer's extra traffic: e.g. 128 tiles -> 2 slices (one full round), not 3 (a full and a half-empty round)
-            // (up to 16 slices of >= 4 K-tiles when the tiles alone would occupy an eighth of the chip or less: the 8x8 / 16x16 levels of the
+        // (up to 16 slices of >= 4 K-tiles when the tiles alone would occupy an eighth of the chip or less: the 8x8 / 16x16 levels of the
         //  reference's 64x64 preset at batch 1, where a launch is ~25 us of fixed costs and the K loop is all that can shrink)
         const int smax = MT * NT <= 32 ? (int)std::min<long long>(16, KTall / 4) : (int)std::min<long long>(8, KTall / 8);
         double best = 1e30;
@@ -607,7 +618,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : korder_arg) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
-    const int cfg = slim ? 3 : tall ? 2 : wide ? 1 : 0;
+    const int cfg = slim2 ? 5 : slim ? 3 : tall ? 2 : wide ? 1 : 0;
     const int stagger_env = vh_knob(VH_KNOB_CONV_STAGGER);
     k.stagger = stagger_env >= 0 ? stagger_env : (a.stagger == 1 ? 1 : 0);       // default: off (see the kernel's note on `late`)
     const bool chunk = k.korder != 0;

@@ -45,7 +45,8 @@ enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATT
        VH_KNOB_CONV_STAGGER = 5,     // -1: vh_conv_args.stagger (default); 0 never, 1 always
        VH_KNOB_ATTN_PIPE = 6,        // 0: plain instead of software-pipelined attention kernels
        VH_KNOB_ATTN_NOMAX = 7,       // 0: keep the running maximum although logit_bound allows dropping it
-       VH_NUM_KNOBS = 8 };
+       VH_KNOB_CONV_SLIM2 = 8,       // -1 (default): Cout <= 64 layers take the 256x64 two-per-CU tile; 0: the 512x64 one (A/B runs)
+       VH_NUM_KNOBS = 9 };
 int vh_knob(int id);
 // device buffer for the stamps of diagnostic builds (-DVH_CLOCK), set through the knobs "dbg_lo"/"dbg_hi"; null otherwise
 inline unsigned long long* vh_debug_ptr() {
