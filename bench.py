@@ -219,7 +219,7 @@ def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True,
     parity_picks: sample indices for batch_vs_batch1 (after the timed region).  wall_probe: additionally time `steps` steps with
     per-launch events OFF (`wall_ms_unprofiled`) - the latency-bound workloads are judged on wall time over summed kernel time."""
     import vivid_amd  # noqa: F401
-    from vivid_amd.sampler import _context, _step
+    from vivid_amd.sampler import _context, _step, guided_denoise
     kind, R, B, guided, desc = WORKLOADS[name]
     if batch:
         B = batch
@@ -227,15 +227,16 @@ def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True,
     src, noise, geo, cond = make_inputs(R, B, 100 + rank, dev, kind)
     t_steps = rho_schedule()
     sctx = _context(dev)
-    state = {"x": (noise * float(t_steps[0])).contiguous()}
+    state = {"x": (noise * float(t_steps[0])).contiguous(), "serial": bool(profile)}
 
     def step(i):
         j = i % 32
         t_hat, t_next = float(t_steps[j]), float(t_steps[j + 1])
         x = state["x"]
         tt = torch.full((x.shape[0],), t_hat, device=dev)
-        D = net(src, x, tt, geo, cond)
-        ref = gnet(src, x, tt) if gnet is not None else None
+        # (two-stream overlap of net and gnet - the library's default for small evaluations - is held off while per-launch events
+        #  are on: concurrent kernels stretch each other's durations, which would spoil the kernel table)
+        D, ref = guided_denoise(net, gnet, src, x, tt, geo, cond, None, 1.5 if gnet is not None else 1, overlap=False if state["serial"] else None)
         d_cur = torch.empty_like(D)
         x_next = torch.empty_like(x)
         _step(sctx, x, None, D, ref, 1.5 if gnet is not None else 1.0, d_cur, t_hat, t_next, x_next)
@@ -276,6 +277,9 @@ def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True,
             c.profile_enable(False)
     extra = {}
     if wall_probe:
+        state["serial"] = False               # library defaults: what a caller of edm_sampler gets
+        for i in range(2):
+            step(warmup + steps + i)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(steps):
@@ -283,6 +287,8 @@ def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True,
         torch.cuda.synchronize()
         extra["wall_ms_unprofiled"] = 1000.0 * (time.perf_counter() - t1) / steps
         extra["hipgraph"] = bool(getattr(list(net._engine.programs.values())[0].plan, "graph_captured", False))
+        import vivid_amd.sampler as _vs
+        extra["guidance_overlap"] = bool(gnet is not None and 2 * B * R * R <= _vs.GUIDANCE_OVERLAP_MAX_PIXELS)
     if parity_picks:
         tt = torch.full((2 * B,), 5.0, device=dev)
         picks = [i for i in parity_picks if i < B]
@@ -317,8 +323,11 @@ def summarise(res, world):
             # wall time of a step with per-launch events off over the summed kernel durations measured with them on: 1.0 = the GPU
             # never waits for the host or for a dependent launch to start
             out["wall_ms_per_step_unprofiled"] = res["extra"]["wall_ms_unprofiled"]
+            out["evals_per_s_unprofiled"] = 1000.0 / res["extra"]["wall_ms_unprofiled"]
             out["wall_over_kernel"] = res["extra"]["wall_ms_unprofiled"] / ksum
             out["hipgraph_replay"] = res["extra"].get("hipgraph")
+            # small guided evaluations run net and gnet on two HIP streams (vivid_amd.sampler.guided_denoise): wall can then be BELOW the summed kernel time
+            out["guidance_overlap_two_streams"] = res["extra"].get("guidance_overlap")
     if "batch_vs_batch1" in res["extra"]:
         b = res["extra"]["batch_vs_batch1"]
         out["parity"] = {f"batch{b['batch']}_vs_batch1": b["rel_l2_max"], "samples": b["samples"], "tolerance": 2e-5,

@@ -25,8 +25,7 @@ def _net(cfg, seed, dual=True, precision="bf16x3"):
     net = vivid_amd.NVPrecond.from_config(cfg, dual_source=dual, precision=precision)
     net.load_state_dict(vivid_amd.synth_state_dict(cfg, seed=seed), strict=True)
     if cfg.super_res:
-        net.cfg = cfg.__class__(**{**cfg.to_dict(), "noisy_sr": 0.0})
-        net._engine.cfg = net.cfg
+        net.noisy_sr = 0.0          # read per call, like the reference's attribute (training/models.py:658): the goldens were made without it
     return net.to("cuda")
 
 
@@ -78,6 +77,25 @@ def test_sampler_vs_golden(name, precision, golden_dir):
     assert out.shape == g["sampler_out"].shape
     err = rel_l2(out.cpu(), g["sampler_out"])
     assert err < TOL_SAMPLER, (name, err)
+
+
+def test_guidance_on_a_side_stream_changes_nothing():
+    """vivid_amd.sampler.guided_denoise evaluates the guidance net on a second HIP stream when the evaluation is too small to fill
+    the chip (generate_images.py:55-62 runs the two nets one after the other): same kernels, same inputs - bit-identical outputs,
+    also when the streams are reused call after call."""
+    from vivid_amd.sampler import guided_denoise
+    case = CASES["tiny_guided"]
+    net, gnet = _net(case["cfg"], case["seed"]), _net(case["gcfg"], case["seed"] + 1)
+    inp = _cuda(make_inputs(case))
+    for sigma in (7.0, 0.4, 0.02):
+        sig = torch.full((inp["src"].shape[0],), sigma, device="cuda")
+        x = x_for(inp, sigma)
+        D0, r0 = guided_denoise(net, gnet, inp["src"], x, sig, inp["geometry"], guidance=1.5, overlap=False)
+        D1, r1 = guided_denoise(net, gnet, inp["src"], x, sig, inp["geometry"], guidance=1.5, overlap=True)
+        torch.cuda.synchronize()
+        assert torch.equal(D0, D1) and torch.equal(r0, r1)
+    D2, r2 = guided_denoise(net, gnet, inp["src"], x, sig, inp["geometry"], guidance=1, overlap=True)
+    assert r2 is None and torch.equal(D2, D0)
 
 
 def test_uncond_closed_form_equals_zero_features():

@@ -13,7 +13,7 @@ def mk(cfg, seed, dual, prec):
     net = vivid_amd.NVPrecond.from_config(cfg, dual_source=dual, precision=prec)
     net.load_state_dict(vivid_amd.synth_state_dict(cfg, seed=seed))
     if cfg.super_res:
-        net.cfg = cfg.__class__(**{**cfg.to_dict(), "noisy_sr": 0.0}); net._engine.cfg = net.cfg
+        net.noisy_sr = 0.0
     return net.cuda()
 
 

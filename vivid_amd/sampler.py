@@ -14,6 +14,8 @@ caller on this path and is not provided.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -42,6 +44,44 @@ def _step(ctx, x_hat, x_probe, D, Dref, guidance, d_cur, t_hat, t_next, x_next):
     ctx.call("vh_sampler_step", a)
 
 
+_side_streams = {}
+
+# Guidance overlap: up to this many input pixels per evaluation (rows x H x W) the two networks of a guided evaluation run on two
+# HIP streams.  Small evaluations cannot fill 256 CUs (the reference's own base@64 preset at batch 1: every launch uses <= 64
+# workgroups and ~20 us of fixed costs), so the guidance net's launches fit beside the main net's.  Measured on MI355X
+# (profiles/r03_guidance_overlap.txt): base@64 batch 1 / 4 / 8 / 16 / 32 -> 1.38x / 1.27x / 1.21x / 1.12-1.17x / 1.09x; 256x256 batch 1 / 2 -> 1.09x /
+# 1.05x; the headline 256x256 batch 16 -> 1.005x (the chip is full; kept serial there, which also keeps per-kernel timings meaningful).
+# VIVID_GUIDANCE_OVERLAP=0/1 forces it off / on.
+GUIDANCE_OVERLAP_MAX_PIXELS = 32 * 2 * 64 * 64
+
+
+def guided_denoise(net, gnet, src, x, tt, labels=None, conditioning_image=None, features=None, guidance=1, overlap=None):
+    """The sampler's `denoise` closure (generate_images.py:55-62): D = net(src, x, t, labels, cond, inject_features=features) and, when
+    guidance != 1, ref = gnet(src, x, t).  Returns (D, ref or None); the CFG combination itself is part of vh_sampler_step.
+    `overlap` (None = by size, see above): evaluate gnet on a side stream while net runs on the current one."""
+    if guidance == 1 or gnet is None:
+        return net(src, x, tt, labels, conditioning_image, inject_features=features).to(torch.float32).contiguous(), None
+    if overlap is None:
+        env = os.environ.get("VIVID_GUIDANCE_OVERLAP")
+        overlap = (env == "1") if env in ("0", "1") else x.shape[0] * x.shape[-1] * x.shape[-2] <= GUIDANCE_OVERLAP_MAX_PIXELS
+    if not overlap or gnet is net:
+        Dx = net(src, x, tt, labels, conditioning_image, inject_features=features).to(torch.float32).contiguous()
+        return Dx, gnet(src, x, tt).to(torch.float32).contiguous()
+    dev = x.device
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)                                   # x and tt were produced on the main stream
+    with torch.cuda.stream(side):
+        ref = gnet(src, x, tt).to(torch.float32).contiguous()
+    Dx = net(src, x, tt, labels, conditioning_image, inject_features=features).to(torch.float32).contiguous()
+    main.wait_stream(side)
+    ref.record_stream(main)                                  # allocated on the side stream, consumed on the main one
+    return Dx, ref
+
+
 def edm_sampler(
     net, src, noise, labels=None, gnet=None, conditioning_image=None,
     num_steps=32, sigma_min=0.002, sigma_max=80, rho=7, guidance=1,
@@ -62,9 +102,7 @@ def edm_sampler(
 
         def denoise(x, t):
             tt = torch.full((x.shape[0],), float(t), dtype=dtype, device=dev)
-            Dx = net(src, x, tt, labels, conditioning_image, inject_features=features).to(dtype).contiguous()
-            ref = gnet(src, x, tt).to(dtype).contiguous() if guidance != 1 else None            # :61
-            return Dx, ref
+            return guided_denoise(net, gnet, src, x, tt, labels, conditioning_image, features, guidance)   # :55-62
 
         # Time step discretisation (:68-70), in fp32 like the reference.
         idx = torch.arange(num_steps, dtype=dtype)
