@@ -98,6 +98,42 @@ def test_guidance_on_a_side_stream_changes_nothing():
     assert r2 is None and torch.equal(D2, D0)
 
 
+@pytest.mark.parametrize("name,extra", [("tiny_guided", {}), ("tiny_dual", {"S_churn": 2.0}), ("tiny_sr", {}), ("tiny_vanilla", {})])
+def test_sampler_feature_pipeline_changes_nothing(name, extra, monkeypatch):
+    """edm_sampler evaluates the encoder once per noise level, ahead on a side stream, and the UNet on its features in place
+    (vivid_amd.sampler._FeaturePipeline); the reference calls the whole net every time (generate_images.py:55-62).  Same kernels on
+    the same inputs: the samples are bit-identical, with guidance, with churn (no two calls share a level) and for the SR net."""
+    import vivid_amd
+    from vivid_amd import sampler as S
+    case = CASES[name]
+    dual = not case.get("snapshot", False)
+    net = _net(case["cfg"], case["seed"], dual)
+    gnet = _net(case["gcfg"], case["seed"] + 1, dual) if "gcfg" in case else None
+    inp = _cuda(make_inputs(case))
+    kw = dict(labels=inp["geometry"], gnet=gnet, conditioning_image=inp.get("cond"), **{**case["sampler"], **extra})
+    made = []
+    orig = S._FeaturePipeline
+
+    class Spy(orig):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    monkeypatch.setattr(S, "_FeaturePipeline", Spy)
+    a = vivid_amd.edm_sampler(net, inp["src"], inp["noise"], randn_like=make_randn_like(case["seed"]), **kw)
+    assert len(made) == 1
+    n_calls, n_levels = len(made[0].levels), len(set(made[0].levels))
+    assert made[0].encoder_evals == sum(1 for i, v in enumerate(made[0].levels) if i == 0 or v != made[0].levels[i - 1]) <= n_calls
+    if not extra.get("S_churn"):
+        assert made[0].encoder_evals == n_levels == case["sampler"]["num_steps"]       # one per step instead of 2N-1
+    else:
+        assert made[0].encoder_evals == n_calls == 2 * case["sampler"]["num_steps"] - 1   # churn: t_hat != the previous t_next
+    monkeypatch.setenv("VIVID_FEATURE_PIPELINE", "0")
+    b = vivid_amd.edm_sampler(net, inp["src"], inp["noise"], randn_like=make_randn_like(case["seed"]), **kw)
+    assert len(made) == 1
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+
+
 def test_uncond_closed_form_equals_zero_features():
     """The n_zero_keys closed form must equal running attention over explicit zero features."""
     case = CASES["tiny_guided"]

@@ -30,9 +30,14 @@ class _Recorder:
         self.no_time_enc = net.no_time_enc
         self.img_resolution, self.img_channels = net.img_resolution, net.img_channels
 
+        self.uncond = net.uncond
+
     def __call__(self, src, x, t, *a, **kw):
         self.xs.append(x[::2].clone())
         return self.net(src, x, t, *a, **kw)
+
+    def encode_features(self, *a, **kw):          # the sampler's split evaluation (encoder ahead on a side stream, one per noise level)
+        return self.net.encode_features(*a, **kw)
 
 
 def _ocfg(cfg):

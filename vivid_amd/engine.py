@@ -163,7 +163,11 @@ class Engine:
         (the reference repeats this on every forward, training/models.py:115-120)."""
         self._ensure_ctx(device)
         self.zeros = torch.zeros(16384, dtype=torch.float32, device=device)     # 64 KiB zero page for vh_conv
-        self.scratch = torch.empty(16 << 20, dtype=torch.float32, device=device) if self.glds else None   # split-K partial sums (64 MiB)
+        # split-K partial sums (64 MiB each): one for the encoder's launches, one for the UNet's - the two halves of a split evaluation
+        # (NVPrecond.encode_features / forward(inject_features=handle)) run on different streams at the same time
+        self.scratch_enc = torch.empty(16 << 20, dtype=torch.float32, device=device) if self.glds else None
+        self.scratch_unet = torch.empty(16 << 20, dtype=torch.float32, device=device) if self.glds else None
+        self.scratch = self.scratch_unet
         self.W.clear()
         self.embW.clear()
         self.programs.clear()
@@ -603,12 +607,18 @@ class Engine:
         return x, out_feats
 
     # ------------------------------------------------------------------ program construction
-    def program(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None) -> Program:
+    def program(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None, slot: int = 0) -> Program:
         """mode: 'full' (encoder + unet), 'features' (encoder only), 'inject' (unet with supplied
-        features), 'uncond' (unet, zero features in closed form)."""
-        key = (mode, B, has_cond, want_logvar)
+        features), 'uncond' (unet, zero features in closed form), 'bound' (unet reading the feature buffers of THIS engine's
+        'features' program of the same `slot` in place - fp32 and S8 copies, no transfer: the split evaluation of
+        NVPrecond.encode_features / forward(inject_features=<handle>)).  `slot` (0 / 1) selects one of two independent
+        'features' / 'bound' program pairs, so that the encoder can fill one feature set while a UNet evaluation reads the other."""
+        key = (mode, B, has_cond, want_logvar, slot)
         if key in self.programs:
             return self.programs[key]
+        ext = None
+        if mode == "bound":
+            ext = self.program("features", B, has_cond, False, slot=slot).io["features_pairs"]
         peak = 0
         prog = None
         for emit in (False, True):
@@ -622,7 +632,7 @@ class Engine:
                 if self.hook is None:
                     self.ctx.plan_begin()
             try:
-                io = self._walk(mode, B, has_cond, want_logvar, fill if emit else None)
+                io = self._walk(mode, B, has_cond, want_logvar, fill if emit else None, ext)
             except BaseException:
                 # an op was refused (unsupported shape, alignment): leave the engine and the context usable and the real error
                 # visible - state first, then the abort, whose own failure (e.g. a sticky HIP error) must not replace the cause
@@ -647,7 +657,7 @@ class Engine:
             self.programs[key] = prog
         return prog
 
-    def _walk(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None) -> Dict[str, object]:
+    def _walk(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None, ext_feats=None) -> Dict[str, object]:
         cfg = self.cfg
         R = cfg.img_resolution
         rm = self.nsrc if self.dual else 1          # rows per target sample in src/x/sigma/geometry
@@ -672,6 +682,8 @@ class Engine:
             fin = [self._alloc(rows_all, r, r, c) for (c, r) in self._feature_shapes()]
             io["features_in"] = fin
             feats = [(f, None) for f in fin]
+        if mode == "bound":
+            feats = list(ext_feats)           # (fp32, S8) buffers that live in the 'features' program's workspace: read in place, never freed here
         if fill is not None:                  # debug (immediate) mode: inputs must be in place before ops run
             fill(Program(None, self._backing, io))
 
@@ -696,6 +708,7 @@ class Engine:
 
         if need_enc:
             spec = self.enc_spec
+            self.scratch = getattr(self, "scratch_enc", None)
             segs = [(io["src"], 0, 3 if cfg.warp_depth_coor else src_c, src_c, 1, 0)]
             if cfg.warp_depth_coor:
                 segs.append((sgrid, 1, 128, 128, 1, 0))
@@ -709,10 +722,12 @@ class Engine:
                 self._free(last)
             self._free(cvec)
             io["features_out"] = [f[0] for f in feats]
+            io["features_pairs"] = list(feats)
         self._free(sgrid)
 
         if need_unet:
             spec = self.unet_spec
+            self.scratch = getattr(self, "scratch_unet", None)
             segs = [(io["x"], 0, cfg.img_channels, cfg.img_channels, rm, 1)]
             if cfg.warp_depth_coor:
                 segs.append((dgrid, 1, 128, 128, rm, 0))

@@ -65,6 +65,14 @@ class _Node(torch.nn.Module):
         super().register_buffer(name, tensor, persistent=persistent)
 
 
+class FeatureHandle:
+    """Encoder features that stay inside the engine (NVPrecond.encode_features): no NCHW copies, no re-split for the matrix
+    kernels.  Valid until the same net encodes into the same `slot` again."""
+
+    def __init__(self, net, slot, B, version):
+        self.net, self.slot, self.B, self.version = net, slot, B, version
+
+
 class NVPrecond(torch.nn.Module):
     def __init__(self, img_resolution, img_channels, source_label_dim, target_label_dim,
                  use_fp16=True, sigma_data=0.5, logvar_channels=128, super_res=False, no_time_enc=None,
@@ -188,6 +196,45 @@ class NVPrecond(torch.nn.Module):
         self._engine.prepare_weights(params, device)
         self._prepared_fp = fp
 
+    # -- split evaluation -------------------------------------------------------------------
+    @torch.no_grad()
+    def encode_features(self, src, sigma, geometry=None, conditioning_image=None, slot: int = 0) -> FeatureHandle:
+        """The encoder half of forward() (training/models.py:664-667: `features = self.encoder(src, c_noise * ..., geometry)`) on the
+        current stream, leaving the features in the engine.  Pass the handle as `inject_features` to evaluate the UNet half on
+        them in place.  The encoder sees (src, sigma, geometry) only - never the noisy image - so a sampler can compute the
+        features of its NEXT noise level on a side stream while this level's UNet runs, and share one encoder evaluation between
+        the calls it makes at the same level (vivid_amd.sampler).  Two slots: one can be filled while the other is read."""
+        cfg, eng = self.cfg, self._engine
+        if cfg.uncond:
+            raise RuntimeError("an uncond net has no encoder")
+        dev = src.device
+        if dev.type != "cuda":
+            raise RuntimeError("vivid_amd.NVPrecond runs on MI355X only: inputs must be on a GPU device")
+        with torch.cuda.device(dev):
+            self._prepare(dev)
+            rm = 2 if self.dual_source else 1
+            rows = src.shape[0]
+            if rows % rm:
+                raise ValueError(f"dual-source input needs an even number of rows, got {rows}")
+            B, R = rows // rm, cfg.img_resolution
+            src_c = 3 + int(cfg.depth_input or cfg.warp_depth_coor)
+            if cfg.warp_depth_coor:
+                assert src.shape[1] == 4, "warp_depth_coor requires depth channel in src"      # :644
+            if geometry is None:
+                raise TypeError("geometry is required (the reference multiplies None by an int here, :631)")
+            prog = eng.program("features", B, bool(cfg.super_res), False, slot=slot)
+            self._put(prog, "sigma", sigma.reshape(-1), (rows,))
+            self._put(prog, "geometry", geometry.reshape(rows, -1), (rows, cfg.source_label_dim))
+            self._put(prog, "src", src, (rows, src_c, R, R))
+            prog.plan.run()
+            return FeatureHandle(self, slot, B, self._prepared_fp)
+
+    @staticmethod
+    def _put(prog, name, t, shape):
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} shape {tuple(t.shape)} != {tuple(shape)}")
+        prog.view(name).copy_(t.to(torch.float32))
+
     # -- forward ---------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, src, dst, sigma, geometry=None, conditioning_image=None, force_fp32=False,
@@ -221,6 +268,13 @@ class NVPrecond(torch.nn.Module):
                 if not cfg.uncond and not (not self.dual_source):
                     raise TypeError("geometry is required (the reference multiplies None by an int here, :631)")
                 geometry = torch.zeros(rows, cfg.source_label_dim, device=dev)
+            handle = inject_features if isinstance(inject_features, FeatureHandle) else None
+            if handle is not None:
+                if handle.net is not self or handle.B != B or handle.version != self._prepared_fp:
+                    raise ValueError("inject_features: this handle belongs to another net, batch size or weight version")
+                if return_features:
+                    prog = eng.program("features", B, has_cond, False, slot=handle.slot)
+                    return [v.clone().permute(0, 3, 1, 2) for v in prog.view("features_out")]
             if return_features:
                 if inject_features is not None:
                     return list(inject_features)
@@ -228,6 +282,8 @@ class NVPrecond(torch.nn.Module):
                     mode = None
                 else:
                     mode = "features"
+            elif handle is not None:
+                mode = "bound"
             elif inject_features is not None:
                 mode = "inject"
             elif cfg.uncond:
@@ -236,12 +292,10 @@ class NVPrecond(torch.nn.Module):
                 mode = "full"
             if mode is None:     # uncond net asked for features: the zero list of :727-736
                 return [torch.zeros(rows, c, r, r, device=dev) for (c, r) in eng._feature_shapes()]
-            prog = eng.program(mode, B, has_cond, bool(return_logvar))
+            prog = eng.program(mode, B, has_cond, bool(return_logvar), slot=handle.slot if handle is not None else 0)
 
             def put(name, t, shape):
-                if tuple(t.shape) != tuple(shape):
-                    raise ValueError(f"{name} shape {tuple(t.shape)} != {tuple(shape)}")
-                prog.view(name).copy_(t.to(torch.float32))
+                self._put(prog, name, t, shape)
 
             put("sigma", sigma.reshape(-1), (rows,))
             put("geometry", geometry.reshape(rows, -1), (rows, cfg.source_label_dim))

@@ -46,6 +46,14 @@ def _step(ctx, x_hat, x_probe, D, Dref, guidance, d_cur, t_hat, t_next, x_next):
 
 _side_streams = {}
 
+
+def _side_stream(dev, name):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), name)
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=dev)
+    return st
+
 # Guidance overlap: up to this many input pixels per evaluation (rows x H x W) the two networks of a guided evaluation run on two
 # HIP streams.  Small evaluations cannot fill 256 CUs (the reference's own base@64 preset at batch 1: every launch uses <= 64
 # workgroups and ~20 us of fixed costs), so the guidance net's launches fit beside the main net's.  Measured on MI355X
@@ -69,10 +77,7 @@ def guided_denoise(net, gnet, src, x, tt, labels=None, conditioning_image=None, 
         return Dx, gnet(src, x, tt).to(torch.float32).contiguous()
     dev = x.device
     main = torch.cuda.current_stream(dev)
-    key = (dev.index if dev.index is not None else torch.cuda.current_device())
-    side = _side_streams.get(key)
-    if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=dev)
+    side = _side_stream(dev, "guidance")
     side.wait_stream(main)                                   # x and tt were produced on the main stream
     with torch.cuda.stream(side):
         ref = gnet(src, x, tt).to(torch.float32).contiguous()
@@ -80,6 +85,62 @@ def guided_denoise(net, gnet, src, x, tt, labels=None, conditioning_image=None, 
     main.wait_stream(side)
     ref.record_stream(main)                                  # allocated on the side stream, consumed on the main one
     return Dx, ref
+
+
+class _FeaturePipeline:
+    """Encoder features for the sampler's sequence of noise levels.
+
+    The encoder half of NVPrecond sees (src, sigma, geometry) only - never the noisy image (training/models.py:664-667) - and
+    the sampler's noise levels are known before its first call (generate_images.py:68-70, :78-84).  Hence:
+      * calls at the same level share ONE encoder evaluation.  Without churn the Heun probe of step i (at t_next) and the Euler
+        call of step i+1 (t_hat = t_cur = that t_next) are such a pair: 32 encoder evaluations per 32-step run instead of 63 -
+        the reference recomputes identical features there;
+      * the features of the next level are computed on a side stream while this level's UNet (and guidance net) run.
+    Results are bit-identical to calling net(src, x, t, labels, cond) every time: the same kernels on the same inputs."""
+
+    def __init__(self, net, src, labels, cond, levels, dtype, dev):
+        self.net, self.src, self.labels, self.cond, self.levels, self.dtype, self.dev = net, src, labels, cond, levels, dtype, dev
+        self.stream = _side_stream(dev, "enc")
+        self.cur = None            # (level, handle)
+        self.ahead = None          # (level, handle, event): launched, not yet consumed
+        self.slot = 0
+        self.encoder_evals = 0
+
+    def _launch(self, level):
+        main = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(main)        # everything enqueued so far - incl. the UNet call that still reads this slot's previous features
+        slot, self.slot = self.slot, self.slot ^ 1
+        with torch.cuda.stream(self.stream):
+            tt = torch.full((self.src.shape[0],), float(level), dtype=self.dtype, device=self.dev)
+            h = self.net.encode_features(self.src, tt, self.labels, self.cond, slot=slot)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.encoder_evals += 1
+        return h, ev
+
+    def features(self, k):
+        """Handle for call k (levels[k]); the main stream is made to wait for its encoder."""
+        level = self.levels[k]
+        if self.cur is None or self.cur[0] != level:
+            if self.ahead is not None and self.ahead[0] == level:
+                _, h, ev = self.ahead
+            else:
+                h, ev = self._launch(level)
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self.cur, self.ahead = (level, h), None
+        if self.ahead is None:
+            for j in range(k + 1, len(self.levels)):
+                if self.levels[j] != level:
+                    self.ahead = (self.levels[j],) + self._launch(self.levels[j])
+                    break
+        return self.cur[1]
+
+
+def _pipeline_capable(net, src) -> bool:
+    env = os.environ.get("VIVID_FEATURE_PIPELINE")
+    if env == "0":
+        return False
+    return hasattr(net, "encode_features") and not getattr(net, "uncond", None) and not getattr(net, "no_time_enc", None)
 
 
 def edm_sampler(
@@ -100,14 +161,30 @@ def edm_sampler(
             features = net(src, torch.zeros_like(src), torch.ones(src.shape[0], dtype=dtype, device=dev), labels,
                            conditioning_image, return_features=True)
 
-        def denoise(x, t):
-            tt = torch.full((x.shape[0],), float(t), dtype=dtype, device=dev)
-            return guided_denoise(net, gnet, src, x, tt, labels, conditioning_image, features, guidance)   # :55-62
-
         # Time step discretisation (:68-70), in fp32 like the reference.
         idx = torch.arange(num_steps, dtype=dtype)
         t_steps = (sigma_max ** (1 / rho) + idx / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
         t_steps = torch.cat([t_steps, torch.zeros_like(t_steps[:1])])
+
+        # The noise level of every denoiser call of this run, in call order (Euler call at t_hat, Heun probe at t_next; :78-84, :104)
+        pipe, calls = None, [0]
+        if features is None and _pipeline_capable(net, src):
+            levels = []
+            for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
+                churn = S_churn > 0 and S_min <= t_cur <= S_max
+                levels.append(float(t_cur + min(S_churn / num_steps, np.sqrt(2) - 1) * t_cur) if churn else float(t_cur))
+                if i < num_steps - 1:
+                    levels.append(float(t_next))
+            pipe = _FeaturePipeline(net, src, labels, conditioning_image, levels, dtype, dev)
+
+        def denoise(x, t):
+            tt = torch.full((x.shape[0],), float(t), dtype=dtype, device=dev)
+            f = features
+            if pipe is not None:
+                assert pipe.levels[calls[0]] == float(t), "noise-level schedule out of step with the sampler loop"
+                f = pipe.features(calls[0])
+                calls[0] += 1
+            return guided_denoise(net, gnet, src, x, tt, labels, conditioning_image, f, guidance)   # :55-62
 
         x_next = (noise.to(dtype) * t_steps[0].item()).contiguous()
         dual = False
