@@ -24,6 +24,7 @@ Prints ONE JSON line on rank 0.  Besides BASELINE's metric it carries, at N = 1:
                     configs[4] (base + depth-warp features at 256^2, B=16), and of the reference's own cascade stages (base@64 +
                     guidance at batch 32 and batch 1, SR@256 at batch 32) with `wall_over_kernel`; each bf16x3 one carries
                     `parity.batchN_vs_batch1`; `--no-extras` skips them
+  sampler_runs      whole edm_sampler runs of the reference's cascade with the library's sampler-level scheduling on and off
 """
 import argparse
 import gc
@@ -304,6 +305,43 @@ def run_workload(name, precision, steps, warmup, dev, rank, world, profile=True,
     return res, None
 
 
+def sampler_run(kind, R, B, num_steps, guided, precision, dev):
+    """Whole edm_sampler runs (generate_images.py:43-118) with the library's defaults and with its sampler-level scheduling switched
+    off: (a) encoder features computed once per noise level, ahead on a side stream (a 32-step run calls the denoiser 63 times at 32
+    distinct levels; the reference re-evaluates the encoder at every call), (b) guidance net on a second stream for small batches.
+    Both are exact (bit-identical samples, tests/test_hip_denoiser.py); neither touches the headline metric, whose timed step is
+    always one full evaluation."""
+    import vivid_amd
+    net, gnet = build_nets(kind, R, precision, dev, guided)
+    src, noise, geo, cond = make_inputs(R, B, 7, dev, kind)
+    kw = dict(labels=geo, gnet=gnet if guided else net, conditioning_image=cond, guidance=1.5 if guided else 1)
+    out = {"workload": f"edm_sampler, {num_steps} steps = {2 * num_steps - 1} denoiser calls, {'CFG 1.5' if guided else 'no guidance'}, batch {B}, {R}x{R}",
+           "calls": 2 * num_steps - 1}
+    for label, env in (("reference_call_pattern", {"VIVID_FEATURE_PIPELINE": "0", "VIVID_GUIDANCE_OVERLAP": "0"}), ("library_default", {})):
+        saved = {k: os.environ.get(k) for k in ("VIVID_FEATURE_PIPELINE", "VIVID_GUIDANCE_OVERLAP")}
+        for k in saved:
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            vivid_amd.edm_sampler(net, src, noise, num_steps=2, **kw)          # records the programs
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            x = vivid_amd.edm_sampler(net, src, noise, num_steps=num_steps, **kw)
+            torch.cuda.synchronize()
+            sec = time.perf_counter() - t0
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = v
+        out[label] = {"seconds": sec, "denoiser_calls_per_s": (2 * num_steps - 1) / sec, "images_per_s": B / sec, "finite": bool(torch.isfinite(x).all().item())}
+    out["speedup"] = out["reference_call_pattern"]["seconds"] / out["library_default"]["seconds"]
+    del net, gnet
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
 def summarise(res, world):
     """The compact form used for the secondary workloads."""
     out = {"workload": res["desc"], "precision": res["precision"], "dtype": "bf16x3" if res["precision"] == "bf16x3" else "f32",
@@ -372,6 +410,9 @@ def main():
             dist.init_process_group(backend)
 
     torch.set_grad_enabled(False)
+    for kv in filter(None, os.environ.get("VIVID_BENCH_KNOBS", "").split(",")):       # A/B runs only: "name=value,..." -> vh_set_knob
+        from vivid_amd import _lib
+        _lib.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
     headline = args.workload == "c2" and not args.batch
     want_parity = world == 1 and not args.no_cpu_baseline and WORKLOADS[args.workload][0] == "base" and WORKLOADS[args.workload][3]
     res, nets = run_workload(args.workload, args.precision, args.steps, args.warmup, dev, rank, world, profile=not args.no_profile,
@@ -459,6 +500,11 @@ def main():
             r2, _ = run_workload(wl, prec, k, w, dev, rank, world, profile=not args.no_profile, parity_picks=picks, wall_probe=probe)
             extras[key] = summarise(r2, world)
         out["other_workloads"] = extras
+        # whole sampler runs of the reference's own cascade (base@64 with guidance, 32 steps; SR@256, 16 steps; generate_images.py:305-327)
+        out["sampler_runs"] = {
+            "ref_base64_b32": sampler_run("base", 64, 32, 32, True, "bf16x3", dev), "ref_sr256_b32": sampler_run("sr", 256, 32, 16, False, "bf16x3", dev),
+            "ref_base64_b1": sampler_run("base", 64, 1, 32, True, "bf16x3", dev), "ref_sr256_b1": sampler_run("sr", 256, 1, 16, False, "bf16x3", dev),
+            "c2_base256_b16_8steps": sampler_run("base", 256, 16, 8, True, "bf16x3", dev)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -679,9 +679,17 @@ def test_psnr_sum(ctx):
     x = torch.randint(0, 256, (3, 3, 16, 16), generator=g, dtype=torch.uint8)
     y = torch.randint(0, 256, (3, 3, 16, 16), generator=g, dtype=torch.uint8)
     want = float((10 * torch.log10(255 ** 2 / ((x.float() - y.float()) ** 2).mean((1, 2, 3)))).double().sum())
+    seen = []
     for dt, conv in ((0, lambda t: t.cuda()), (1, lambda t: t.float().cuda())):
-        acc = torch.zeros(1, dtype=torch.float64, device="cuda")
-        xd, yd = conv(x), conv(y)
-        ctx.call("vh_psnr_sum", L.PsnrArgs(x=xd.data_ptr(), y=yd.data_ptr(), images=3, elems=3 * 16 * 16, dtype=dt, acc=acc.data_ptr()))
-        torch.cuda.synchronize()
-        assert abs(float(acc) - want) < 1e-5 * abs(want)
+        for _ in range(2):                           # per-image values are folded into acc in index order: bit-reproducible
+            acc = torch.zeros(1, dtype=torch.float64, device="cuda")
+            per = torch.empty(3, dtype=torch.float64, device="cuda")
+            xd, yd = conv(x), conv(y)
+            ctx.call("vh_psnr_sum", L.PsnrArgs(x=xd.data_ptr(), y=yd.data_ptr(), images=3, elems=3 * 16 * 16, dtype=dt, acc=acc.data_ptr(),
+                                               per_image=per.data_ptr()))
+            torch.cuda.synchronize()
+            assert abs(float(acc) - want) < 1e-5 * abs(want)
+            seen.append(float(acc))
+    assert seen[0] == seen[1] and seen[2] == seen[3]
+    with pytest.raises(L.VividHipError):
+        ctx.call("vh_psnr_sum", L.PsnrArgs(x=xd.data_ptr(), y=yd.data_ptr(), images=3, elems=3 * 16 * 16, dtype=1, acc=acc.data_ptr(), per_image=None))

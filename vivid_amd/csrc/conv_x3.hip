@@ -613,7 +613,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // +1.6 % at 0.2 GB, -2 % at 67 MB (the per-K-tile pointer selection costs VALU and buys nothing there).
     // vh_conv_args.korder overrides the size rule; the process-wide knob "conv_korder" (0 tap / 1 chunk) overrides both (A/B runs).
     const int korder_env = vh_knob(VH_KNOB_CONV_KORDER);
-    const bool big_input = (double)M * a.cin_pad * 4.0 > 1.5e8;
+    const bool big_input = (double)M * a.cin_pad * 4.0 > 1e6 * (double)vh_knob(VH_KNOB_CONV_KORDER_MB);
     const int korder_arg = a.korder == VH_KORDER_TAP ? 0 : a.korder == VH_KORDER_CHUNK ? 1 : (big_input ? 1 : 0);
     k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : korder_arg) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);

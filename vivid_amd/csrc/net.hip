@@ -1,0 +1,718 @@
+// vh_net: one whole NVPrecond evaluation behind the C ABI (include/vivid_hip.h, "whole-network evaluation").
+//
+// reference: NVPrecond._forward_dualsource training/models.py:628-689 (and the single-source forward :691-749) ->
+// UNetEncoder.forward :536-570 -> XAttnUNet.forward :483-518 -> Block.forward :165-206 / XAttnBlock.forward :251-315, on the
+// architecture tables UNet.__init__ builds (:322-384, :413-480, :524-534, :576-582).
+//
+// This is the production walk of vivid_amd/engine.py restated in C++ for hosts without Python: bf16x3 arithmetic on the
+// direct-to-LDS convolution kernels with the fused q/k/v epilogue, default [1,1] resample filter, modes "full" (encoder + UNet)
+// and "uncond" (UNet with the zero features in closed form).  It emits the SAME op sequence with the same arguments as the Python
+// engine (tests/test_hip_net_c.py compares the two outputs bit for bit), records it once per batch size into a vh_plan over a
+// caller-supplied workspace, and replays it; nothing is allocated inside a call.
+#include "ctx.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+
+namespace {
+
+constexpr double LOG2E = 1.4426950408889634;
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------- architecture table (training/models.py:322-384, 413-480, 524-534)
+struct Block {
+    std::string name;
+    bool conv = false;            // bare first MPConv 3x3
+    int cin = 0, cout = 0, res = 0;
+    bool dec = false;
+    int resample = 0;             // 0 keep, 1 up, 2 down
+    int heads = 0;
+    bool xattn = false, takes_skip = false, live = true;
+};
+struct Spec {
+    int in_channels = 0, label_dim = 0, cnoise = 0, cemb = 0, out_channels = 0, last_ch = 0;
+    std::vector<Block> enc, dec;
+};
+
+Spec make_spec(const vh_net_config& c, bool encoder) {
+    Spec s;
+    const int R = c.img_resolution;
+    const int warp = c.logvar_channels * (c.warp_depth_coor ? 1 : 0);
+    int img_ch, cph;
+    if (encoder) { img_ch = c.img_channels + (c.depth_input ? 1 : 0) + warp; s.label_dim = c.source_label_dim; cph = 64; s.in_channels = img_ch + 1; }
+    else {
+        img_ch = c.img_channels + warp; s.label_dim = c.target_label_dim; cph = c.super_res ? 32 : 64; s.in_channels = img_ch + 1;
+        if (c.super_res) s.in_channels = 2 * (s.in_channels - 1) + 1;
+    }
+    std::vector<int> cblock;
+    for (int i = 0; i < c.num_levels; ++i) cblock.push_back(c.model_channels * c.channel_mult[i]);
+    s.cnoise = c.channel_mult_noise > 0 ? c.model_channels * c.channel_mult_noise : cblock[0];
+    s.cemb = c.channel_mult_emb > 0 ? c.model_channels * c.channel_mult_emb : *std::max_element(cblock.begin(), cblock.end());
+    const bool xattn = !encoder;
+    auto is_attn_res = [&](int res) { for (int i = 0; i < c.num_attn_resolutions; ++i) if (c.attn_resolutions[i] == res) return true; return false; };
+    auto rname = [](int res, const char* what, int idx = -1) {
+        std::string n = std::to_string(res) + "x" + std::to_string(res) + "_" + what;
+        if (idx >= 0) n += std::to_string(idx);
+        return n;
+    };
+    int cout = s.in_channels;
+    const int L = (int)cblock.size();
+    for (int level = 0; level < L; ++level) {
+        const int ch = cblock[level], res = R >> level;
+        if (level == 0) { Block b; b.name = rname(res, "conv"); b.conv = true; b.cin = cout; b.cout = ch; b.res = res; s.enc.push_back(b); cout = ch; }
+        else { Block b; b.name = rname(res, "down"); b.cin = b.cout = cout; b.res = res; b.resample = 2; s.enc.push_back(b); }
+        for (int idx = 0; idx < c.num_blocks; ++idx) {
+            Block b; b.name = rname(res, "block", idx); b.cin = cout; b.cout = cout = ch; b.res = res;
+            const bool attn = is_attn_res(res) || (c.extra_attn >= 0 && c.extra_attn == idx && level != 0);
+            b.heads = attn ? cout / cph : 0; b.xattn = xattn && attn;
+            s.enc.push_back(b);
+        }
+    }
+    std::vector<int> skips;
+    for (auto& b : s.enc) skips.push_back(b.cout);
+    for (int level = L - 1; level >= 0; --level) {
+        const int ch = cblock[level], res = R >> level;
+        if (level == L - 1) {
+            Block b0; b0.name = rname(res, "in", 0); b0.cin = b0.cout = cout; b0.res = res; b0.dec = true; b0.heads = cout / cph; b0.xattn = xattn; s.dec.push_back(b0);
+            Block b1; b1.name = rname(res, "in", 1); b1.cin = b1.cout = cout; b1.res = res; b1.dec = true; s.dec.push_back(b1);
+        } else { Block b; b.name = rname(res, "up"); b.cin = b.cout = cout; b.res = res; b.dec = true; b.resample = 1; s.dec.push_back(b); }
+        for (int idx = 0; idx <= c.num_blocks; ++idx) {
+            const int sk = skips.back(); skips.pop_back();
+            Block b; b.name = rname(res, "block", idx); b.cin = cout + sk; b.cout = cout = ch; b.res = res; b.dec = true; b.takes_skip = true;
+            const bool attn = is_attn_res(res) || (c.extra_attn >= 0 && c.extra_attn == c.num_blocks - idx && level != 0);
+            b.heads = attn ? cout / cph : 0; b.xattn = xattn && attn;
+            s.dec.push_back(b);
+        }
+    }
+    s.last_ch = cout;
+    if (!encoder) s.out_channels = 3;
+    else for (int i = (int)s.dec.size() - 1; i >= 0 && s.dec[i].heads == 0; --i) s.dec[i].live = false;      // :530-534
+    return s;
+}
+
+// ---------------------------------------------------------------- parameters (the reference's state_dict keys)
+struct Param { std::string name; int ndim; int shape[4]; const float* ptr = nullptr; };
+
+void spec_params(const Spec& sp, const std::string& prefix, bool has_out_gain, std::vector<Param>& out) {
+    auto add = [&](const std::string& n, std::initializer_list<int> shp) {
+        Param p; p.name = n; p.ndim = (int)shp.size(); int i = 0; for (int v : shp) p.shape[i++] = v; for (; i < 4; ++i) p.shape[i] = 1; out.push_back(p);
+    };
+    if (has_out_gain) add(prefix + "out_gain", {});
+    add(prefix + "emb_fourier.freqs", {sp.cnoise});
+    add(prefix + "emb_fourier.phases", {sp.cnoise});
+    add(prefix + "emb_noise.weight", {sp.cemb, sp.cnoise});
+    if (sp.label_dim) add(prefix + "emb_label.weight", {sp.cemb, sp.label_dim});
+    for (int g = 0; g < 2; ++g)
+        for (const Block& b : (g ? sp.dec : sp.enc)) {
+            if (!b.live) continue;
+            const std::string p = prefix + (g ? "dec." : "enc.") + b.name + ".";
+            if (b.conv) { add(p + "weight", {b.cout, b.cin, 3, 3}); continue; }
+            add(p + "emb_gain", {});
+            add(p + "conv_res0.weight", {b.cout, b.dec ? b.cin : b.cout, 3, 3});
+            add(p + "emb_linear.weight", {b.cout, sp.cemb});
+            add(p + "conv_res1.weight", {b.cout, b.cout, 3, 3});
+            if (b.cin != b.cout) add(p + "conv_skip.weight", {b.cout, b.cin, 1, 1});
+            if (b.heads) {
+                add(p + "attn_qkv.weight", {3 * b.cout, b.cout, 1, 1});
+                if (b.xattn) add(p + "x_attn_kv.weight", {2 * b.cout, b.cout, 1, 1});
+                add(p + "attn_proj.weight", {b.cout, b.cout, 1, 1});
+            }
+        }
+    if (sp.out_channels) add(prefix + "out_conv.weight", {sp.out_channels, sp.last_ch, 3, 3});
+}
+
+// ---------------------------------------------------------------- workspace arena (first fit, 64-float granules)
+struct Arena {
+    std::vector<std::pair<long long, long long>> free_{{0, 1LL << 62}};
+    long long peak = 0;
+    long long alloc(long long n) {
+        n = (std::max<long long>(n, 1) + 63) / 64 * 64;
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= n) {
+                const long long off = free_[i].first;
+                if (free_[i].second == n) free_.erase(free_.begin() + i); else free_[i] = {off + n, free_[i].second - n};
+                peak = std::max(peak, off + n);
+                return off;
+            }
+        return -1;
+    }
+    void release(long long off, long long n) {
+        n = (std::max<long long>(n, 1) + 63) / 64 * 64;
+        free_.push_back({off, n});
+        std::sort(free_.begin(), free_.end());
+        std::vector<std::pair<long long, long long>> m{free_[0]};
+        for (size_t i = 1; i < free_.size(); ++i)
+            if (m.back().first + m.back().second == free_[i].first) m.back().second += free_[i].second; else m.push_back(free_[i]);
+        free_ = m;
+    }
+};
+struct Buf { long long off = -1; long long n = 0; int c = 0; bool ok() const { return off >= 0; } };   // n floats; c = channels (last dim)
+
+struct Weight { float* wt = nullptr; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0; };
+
+struct Program {
+    int B = 0;
+    vh_plan* plan = nullptr;
+    float* base = nullptr;
+    Buf sigma, geometry, src, x, cond, D;
+    long long peak_floats = 0;
+};
+
+}  // namespace
+
+struct vh_net {
+    vh_ctx* ctx = nullptr;
+    vh_net_config cfg{};
+    bool has_enc = false;
+    Spec enc, unet;
+    std::vector<Param> params;
+    std::map<std::string, int> pindex;
+    // prepared weights (inside the caller's buffer)
+    std::map<std::string, Weight> W;
+    struct EmbW { float* wt = nullptr; std::map<std::string, int> cols; int total = 0; } embE, embU;
+    float* zeros = nullptr; float* scratch_enc = nullptr; float* scratch_unet = nullptr; float* scratch = nullptr;
+    bool prepared = false;
+    std::map<int, std::unique_ptr<Program>> programs;
+    // walk state
+    Arena* A = nullptr; float* base = nullptr; bool emit = false; int rc = VH_OK;
+};
+
+namespace {
+
+constexpr size_t ZEROS_FLOATS = 16384, SCRATCH_FLOATS = size_t(16) << 20;
+
+const float* P(vh_net* n, const std::string& key) {
+    auto it = n->pindex.find(key);
+    return it == n->pindex.end() ? nullptr : n->params[it->second].ptr;
+}
+
+// --------------------------------------------------------------- emission helpers (mirror engine.Engine._alloc/_free/_conv/_split)
+Buf alloc(vh_net* n, long long rows, long long h, long long w, long long c) {
+    Buf b; b.n = rows * h * w * c; b.c = (int)c; b.off = n->A->alloc(b.n);
+    if (b.off < 0 && n->rc == VH_OK) n->rc = vh_fail(VH_EINVAL, "vh_net: arena exhausted");
+    return b;
+}
+void release(vh_net* n, Buf& b) { if (b.ok()) { n->A->release(b.off, b.n); b.off = -1; } }
+float* ptr(vh_net* n, const Buf& b) { return b.ok() ? n->base + b.off : nullptr; }
+template <class F, class A> void call(vh_net* n, F fn, const A& a) { if (n->emit && n->rc == VH_OK) n->rc = fn(n->ctx, &a); }
+
+struct ConvOpt {
+    int up = 0, epi = VH_EPI_STORE; const float* cvec = nullptr; int cvec_ld = 0; const Buf* res = nullptr; int res_up = 0;
+    float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr; bool s8_only = false, also_s8 = false; const vh_qkv_epilogue* qkv = nullptr;
+};
+// bf16x3 glds convolution of an S8 source; returns (fp32 out, S8 out) - either may be empty
+std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, int h, int w, ConvOpt o) {
+    Buf out, out8;
+    if (o.qkv) o.epi = VH_EPI_QKV;
+    if ((o.s8_only || o.also_s8) && !o.qkv) out8 = alloc(n, rows, h, w, W.cout);
+    if (!o.s8_only && !o.qkv) { if (o.out) out = *o.out; else out = alloc(n, rows, h, w, W.cout); }
+    vh_conv_args a{};
+    a.src0 = ptr(n, src); a.src1 = nullptr; a.c0 = src.c; a.c1 = 0; a.scale0 = 1.f; a.scale1 = 1.f;
+    a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = VH_PRO_NONE;
+    a.wt = W.wt; a.cin_pad = W.cin_pad; a.k_pad = W.k_pad; a.zeros = n->zeros; a.zeros_bytes = ZEROS_FLOATS * 4; a.cout = W.cout;
+    a.scratch = n->scratch; a.scratch_floats = SCRATCH_FLOATS;
+    a.out = ptr(n, out); a.out_s8 = ptr(n, out8); a.out_s8_c = out8.ok() ? W.cout : 0;
+    a.prec = VH_PREC_BF16X3; a.kernel = VH_CONV_GLDS256; a.epi = o.epi; a.cvec = o.cvec; a.cvec_ld = o.cvec_ld;
+    a.res = o.res ? ptr(n, *o.res) : nullptr; a.res_up = o.res_up; a.ta = o.ta; a.tb = o.tb; a.clip = o.clip; a.qkv = o.qkv;
+    a.stagger = 0; a.korder = VH_KORDER_AUTO; a.tile = VH_TILE_AUTO;
+    call(n, vh_conv, a);
+    return {out, out8};
+}
+// fp32 NHWC (1-2 sources, mp_cat weights) -> S8; raw_too: second S8 output without the prologue
+std::pair<Buf, Buf> split(vh_net* n, const Buf& s0, float sc0, const Buf* s1, float sc1, long long npix, int rows, int h, int w, int pro, bool raw_too) {
+    const int ctot = s0.c + (s1 ? s1->c : 0), cpad = round_up(ctot, 32);
+    Buf out = alloc(n, rows, h, w, cpad), raw;
+    if (raw_too) raw = alloc(n, rows, h, w, cpad);
+    vh_split_args a{};
+    a.src0 = ptr(n, s0); a.src1 = s1 ? ptr(n, *s1) : nullptr; a.c0 = s0.c; a.c1 = s1 ? s1->c : 0; a.scale0 = sc0; a.scale1 = sc1;
+    a.pro = pro; a.npix = npix; a.c_pad = cpad; a.out = ptr(n, out); a.out_raw = ptr(n, raw);
+    call(n, vh_split, a);
+    return {out, raw};
+}
+void mp_sum_coeffs(float t, float& a, float& b) { const double nn = std::sqrt((1.0 - t) * (1.0 - t) + (double)t * t); a = (float)((1.0 - t) / nn); b = (float)(t / nn); }
+
+struct Feat { Buf f32, s8; };
+
+// Block.forward :165-206 / XAttnBlock.forward :251-315 (bf16x3 path of engine.Engine._block)
+std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, int rows, const Buf& x, const Buf* skip, const Buf& cvec_all,
+                          const vh_net::EmbW& emb, const Feat* feat, int nsrc, float n_zero, bool want_s8) {
+    const vh_net_config& cfg = n->cfg;
+    const std::string p = prefix + (b.dec ? "dec." : "enc.") + b.name + ".";
+    const int R = b.res, C = b.cout, D = b.heads ? C / b.heads : 0;
+    const float* cv = ptr(n, cvec_all) ? ptr(n, cvec_all) + emb.cols.at(p) : (const float*)nullptr;
+    if (!n->emit) cv = reinterpret_cast<const float*>(16);          // (dry walk: never dereferenced)
+    float ta, tb; mp_sum_coeffs(cfg.res_balance, ta, tb);
+    const float clip = cfg.clip_act > 0.f ? cfg.clip_act : 0.f, clip_res = b.heads ? 0.f : clip;
+    const bool has_skip_conv = b.cin != b.cout;
+    const bool res1_s8 = b.heads > 0, fin_s8 = want_s8 && !b.heads;
+    const long long npix = (long long)rows * R * R;
+    Buf out, r_s8, out_s8;
+    if (!b.dec) {
+        Buf xs = alloc(n, rows, R, R, C), xn;
+        vh_pixnorm_args pa{}; pa.rows = rows; pa.h = R; pa.w = R; pa.c = C; pa.norm = 1; pa.out_s8 = nullptr;
+        if (b.resample == 2) {
+            xn = alloc(n, rows, R, R, C);
+            pa.in = ptr(n, x); pa.out = ptr(n, xn); pa.pool = 1; pa.out_s8 = ptr(n, xs);
+            call(n, vh_pixnorm, pa);
+        } else if (has_skip_conv) {
+            auto xr = split(n, x, 1.f, nullptr, 1.f, npix, rows, R, R, VH_PRO_NONE, false);
+            xn = conv(n, xr.first, n->W.at(p + "conv_skip.weight"), rows, R, R, ConvOpt{}).first;
+            release(n, xr.first);
+            pa.in = ptr(n, xn); pa.out = ptr(n, xn); pa.pool = 0; pa.out_s8 = ptr(n, xs);
+            call(n, vh_pixnorm, pa);
+        } else {
+            xn = alloc(n, rows, R, R, C);
+            pa.in = ptr(n, x); pa.out = ptr(n, xn); pa.pool = 0; pa.out_s8 = ptr(n, xs);
+            call(n, vh_pixnorm, pa);
+        }
+        ConvOpt o0; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
+        Buf y = conv(n, xs, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
+        release(n, xs);
+        ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = &xn; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+        auto r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
+        release(n, y); release(n, xn);
+        out = r.first; r_s8 = r.second;
+    } else {
+        const int up = b.resample == 1 ? 1 : 0;
+        float sc0 = 1.f, sc1 = 1.f;
+        if (skip) {                                               // mp_cat :78-84
+            const double t = cfg.concat_balance, Na = x.c, Nb = skip->c;
+            const double Cc = std::sqrt((Na + Nb) / ((1 - t) * (1 - t) + t * t));
+            sc0 = (float)(Cc / std::sqrt(Na) * (1 - t)); sc1 = (float)(Cc / std::sqrt(Nb) * t);
+        }
+        const long long npix_in = up ? npix / 4 : npix;
+        const int Rin = up ? R / 2 : R;
+        auto cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, has_skip_conv);
+        ConvOpt o0; o0.up = up; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
+        Buf y = conv(n, cs.first, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
+        release(n, cs.first);
+        Buf xsk;
+        const Buf* res; int res_up;
+        if (has_skip_conv) {
+            ConvOpt os; os.up = up;
+            xsk = conv(n, cs.second, n->W.at(p + "conv_skip.weight"), rows, R, R, os).first;
+            release(n, cs.second);
+            res = &xsk; res_up = 0;
+        } else { res = &x; res_up = up; }
+        ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = res; o1.res_up = res_up; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+        auto r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
+        release(n, y); release(n, xsk);
+        out = r.first; r_s8 = r.second;
+    }
+    if (fin_s8) out_s8 = r_s8;
+    if (b.heads) {
+        const int S = R * R;
+        const bool use_feat = b.xattn && feat != nullptr;
+        const int kl = use_feat ? S * (1 + nsrc) : S;
+        const float nz = (b.xattn && !use_feat) ? n_zero * S : 0.f;
+        const int klp = round_up(kl, 64);
+        Buf q = alloc(n, rows, b.heads, S, D), k = alloc(n, rows, b.heads, klp, D), v = alloc(n, rows, b.heads, klp, D);
+        vh_qkv_epilogue e{}; e.q = ptr(n, q); e.k = ptr(n, k); e.v = ptr(n, v); e.heads = b.heads; e.nj = 3; e.rows_per_b = 1; e.koff = 0; e.kl = kl;
+        e.qscale = (float)(LOG2E / std::sqrt((double)D));
+        ConvOpt oq; oq.qkv = &e;
+        conv(n, r_s8, n->W.at(p + "attn_qkv.weight"), rows, R, R, oq);
+        release(n, r_s8);
+        if (use_feat) {
+            vh_qkv_epilogue e2{}; e2.q = nullptr; e2.k = ptr(n, k); e2.v = ptr(n, v); e2.heads = b.heads; e2.nj = 2; e2.rows_per_b = nsrc; e2.koff = S; e2.kl = kl; e2.qscale = 1.f;
+            ConvOpt ok; ok.qkv = &e2;
+            conv(n, feat->s8, n->W.at(p + "x_attn_kv.weight"), rows * nsrc, R, R, ok);
+        }
+        Buf att = alloc(n, rows, R, R, C);
+        vh_attention_args aa{}; aa.q = ptr(n, q); aa.k = ptr(n, k); aa.v = ptr(n, v); aa.b = rows; aa.heads = b.heads; aa.s = S; aa.kl = kl; aa.d = D;
+        aa.n_zero_keys = nz; aa.out = ptr(n, att); aa.out_s8 = 1; aa.logit_bound = (float)(LOG2E * std::sqrt((double)D) * 1.001);
+        call(n, vh_attention_x3, aa);
+        release(n, q); release(n, k); release(n, v);
+        float ta2, tb2; mp_sum_coeffs(cfg.attn_balance, ta2, tb2);
+        ConvOpt op; op.epi = VH_EPI_MPSUM; op.res = &out; op.ta = ta2; op.tb = tb2; op.clip = clip; op.out = &out; op.also_s8 = want_s8;
+        auto r2 = conv(n, att, n->W.at(p + "attn_proj.weight"), rows, R, R, op);
+        if (want_s8) out_s8 = r2.second;
+        release(n, att);
+    }
+    return {out, out_s8};
+}
+
+// emb = mp_silu(mp_sum(emb_noise(fourier(c_noise)), emb_label(geometry))) :388-391 and every block's emb_linear in one launch
+Buf embedding(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net::EmbW& emb, int rows, const Buf& sigma, int sigma_stride, float time_scale,
+              const Buf& geometry, int label_dim) {
+    const vh_net_config& cfg = n->cfg;
+    Buf e = alloc(n, rows, 1, 1, sp.cemb);
+    const Weight& wn = n->W.at(prefix + "emb_noise.weight");
+    const bool has_label = sp.label_dim > 0;
+    vh_embed_args a{};
+    a.sigma = ptr(n, sigma); a.sigma_stride = sigma_stride; a.time_scale = time_scale;
+    a.geometry = has_label ? ptr(n, geometry) : nullptr; a.label_dim = has_label ? label_dim : 0; a.geometry_scale = cfg.uncond ? 0.f : 1.f;
+    a.freqs = P(n, prefix + "emb_fourier.freqs"); a.phases = P(n, prefix + "emb_fourier.phases"); a.cnoise = sp.cnoise;
+    a.w_noise = wn.wt; a.w_noise_kpad = wn.k_pad;
+    if (has_label) { const Weight& wl = n->W.at(prefix + "emb_label.weight"); a.w_label = wl.wt; a.w_label_kpad = wl.k_pad; }
+    a.label_balance = cfg.label_balance; a.rows = rows; a.cemb = sp.cemb; a.raw = 0; a.emb = ptr(n, e);
+    call(n, vh_embed, a);
+    Buf cvec = alloc(n, rows, 1, 1, emb.total);
+    vh_linear_args l{}; l.emb = ptr(n, e); l.rows = rows; l.cemb = sp.cemb; l.wt = emb.wt; l.k_pad = round_up(sp.cemb, 32); l.cols = emb.total; l.bias = 1.f; l.out = ptr(n, cvec);
+    call(n, vh_linear, l);
+    release(n, e);
+    return cvec;
+}
+
+// UNetEncoder.forward :536-570 (collect) / XAttnUNet.forward :483-518
+Buf run_unet(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net::EmbW& emb, int rows, Buf x_in, const Buf& cvec,
+             const std::vector<Feat>* feats, bool collect, float n_zero, int nsrc, std::vector<Feat>* out_feats) {
+    std::vector<Buf> skips;
+    size_t fi = 0;
+    Buf x = x_in;
+    auto kept = [&](const Buf& b) { if (out_feats) for (auto& f : *out_feats) if (f.f32.off == b.off) return true; return false; };
+    auto in_skips = [&](const Buf& b) { for (auto& s : skips) if (s.off == b.off) return true; return false; };
+    auto next_feat = [&](const Block& b) -> const Feat* {
+        const Feat* f = nullptr;
+        if (b.xattn) { if (feats) f = &(*feats)[fi]; ++fi; }
+        return f;
+    };
+    for (const Block& b : sp.enc) {
+        Buf nx;
+        if (b.conv) {
+            auto xs8 = split(n, x, 1.f, nullptr, 1.f, (long long)rows * b.res * b.res, rows, b.res, b.res, VH_PRO_NONE, false);
+            nx = conv(n, xs8.first, n->W.at(prefix + "enc." + b.name + ".weight"), rows, b.res, b.res, ConvOpt{}).first;
+            release(n, xs8.first);
+            release(n, x);
+        } else {
+            const Feat* f = next_feat(b);
+            auto r = block(n, prefix, b, rows, x, nullptr, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0);
+            nx = r.first;
+            if (collect && b.heads > 0) out_feats->push_back(Feat{r.first, r.second});
+        }
+        skips.push_back(nx);
+        x = nx;
+    }
+    for (const Block& b : sp.dec) {
+        if (!b.live) break;
+        Buf skip; const Buf* sk = nullptr;
+        if (b.takes_skip) { skip = skips.back(); skips.pop_back(); sk = &skip; }
+        const Feat* f = next_feat(b);
+        auto r = block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0);
+        if (!kept(x) && !in_skips(x)) release(n, x);
+        if (sk && !kept(skip) && !in_skips(skip) && skip.off != x.off) release(n, skip);
+        if (collect && b.heads > 0) out_feats->push_back(Feat{r.first, r.second});
+        x = r.first;
+    }
+    for (auto& s : skips) if (!kept(s) && s.off != x.off) release(n, s);
+    return x;
+}
+
+Buf assemble(vh_net* n, const vh_segment* segs, int nseg, int rows, int R, int c_pad, const Buf& sigma) {
+    Buf out = alloc(n, rows, R, R, c_pad);
+    vh_assemble_args a{};
+    a.nseg = nseg; for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+    a.sigma = ptr(n, sigma); a.sigma_data = n->cfg.sigma_data; a.rows = rows; a.h = R; a.w = R; a.c_pad = c_pad; a.out = ptr(n, out);
+    call(n, vh_assemble, a);
+    return out;
+}
+
+// NVPrecond._forward_dualsource :628-689 / forward :691-749 ("full" when the net has an encoder, "uncond" otherwise)
+void walk(vh_net* n, int B, Program& pr) {
+    const vh_net_config& cfg = n->cfg;
+    const int R = cfg.img_resolution, nsrc = cfg.dual_source ? 2 : 1, rm = nsrc, rows_all = B * rm;
+    const int src_c = 3 + ((cfg.depth_input || cfg.warp_depth_coor) ? 1 : 0);
+    const bool need_enc = n->has_enc;
+    pr.sigma = alloc(n, rows_all, 1, 1, 1);
+    pr.geometry = alloc(n, rows_all, 1, 1, cfg.source_label_dim);
+    if (need_enc || cfg.warp_depth_coor) pr.src = alloc(n, rows_all, src_c, R, R);
+    pr.x = alloc(n, rows_all, cfg.img_channels, R, R);
+    pr.D = alloc(n, B, cfg.img_channels, R, R);
+    if (cfg.super_res) pr.cond = alloc(n, B, cfg.img_channels, R, R);
+    Buf sgrid, dgrid;
+    if (cfg.warp_depth_coor) {                                    // depth-warp Fourier features :643-652
+        sgrid = alloc(n, rows_all, R, R, 128); dgrid = alloc(n, rows_all, R, R, 128);
+        Buf flag = alloc(n, 1, 1, 1, 1);
+        vh_nonzero_args nz{}; nz.in = ptr(n, pr.src); nz.rows = rows_all; nz.c_used = 3; nz.c_total = src_c; nz.hw = R * R; nz.flag = ptr(n, flag);
+        call(n, vh_nonzero_flag, nz);
+        vh_warp_args wa{}; wa.depth = ptr(n, pr.src); wa.src_c = src_c; wa.depth_ch = 3; wa.geometry = ptr(n, pr.geometry);
+        std::memcpy(wa.mean, cfg.geom_mean, sizeof wa.mean); std::memcpy(wa.std, cfg.geom_std, sizeof wa.std);
+        wa.freqs = P(n, "logvar_fourier.freqs"); wa.phases = P(n, "logvar_fourier.phases"); wa.rows = rows_all; wa.s = R;
+        wa.grid_feat = ptr(n, sgrid); wa.warp_feat = ptr(n, dgrid); wa.nonzero_flag = ptr(n, flag);
+        call(n, vh_warp_features, wa);
+        release(n, flag);
+    }
+    std::vector<Feat> feats;
+    if (need_enc) {
+        n->scratch = n->scratch_enc;
+        vh_segment segs[2]; int ns = 0;
+        segs[ns++] = vh_segment{ptr(n, pr.src), 0, cfg.warp_depth_coor ? 3 : src_c, src_c, 1, 0};
+        if (cfg.warp_depth_coor) segs[ns++] = vh_segment{ptr(n, sgrid), 1, 128, 128, 1, 0};
+        Buf xin = assemble(n, segs, ns, rows_all, R, round_up(n->enc.in_channels, 8), pr.sigma);
+        release(n, sgrid);
+        Buf cvec = embedding(n, "encoder.", n->enc, n->embE, rows_all, pr.sigma, 1, cfg.no_time_enc ? 0.f : 1.f, pr.geometry, cfg.source_label_dim);
+        Buf last = run_unet(n, "encoder.", n->enc, n->embE, rows_all, xin, cvec, nullptr, true, 0.f, nsrc, &feats);
+        bool last_kept = false; for (auto& f : feats) if (f.f32.off == last.off) last_kept = true;
+        if (!last_kept) release(n, last);
+        release(n, cvec);
+    }
+    release(n, sgrid);
+    {
+        n->scratch = n->scratch_unet;
+        vh_segment segs[3]; int ns = 0;
+        segs[ns++] = vh_segment{ptr(n, pr.x), 0, cfg.img_channels, cfg.img_channels, rm, 1};
+        if (cfg.warp_depth_coor) segs[ns++] = vh_segment{ptr(n, dgrid), 1, 128, 128, rm, 0};
+        if (cfg.super_res) segs[ns++] = vh_segment{ptr(n, pr.cond), 0, cfg.img_channels, cfg.img_channels, 1, 0};
+        Buf xin = assemble(n, segs, ns, B, R, round_up(n->unet.in_channels, 8), pr.sigma);
+        release(n, dgrid);
+        Buf cvec = embedding(n, "unet.", n->unet, n->embU, B, pr.sigma, rm, 1.f, pr.geometry, cfg.target_label_dim);
+        const float n_zero = need_enc ? 0.f : (float)nsrc;
+        Buf last = run_unet(n, "unet.", n->unet, n->embU, B, xin, cvec, need_enc ? &feats : nullptr, false, n_zero, nsrc, nullptr);
+        auto ls8 = split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false);
+        Buf F = conv(n, ls8.first, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
+        release(n, ls8.first); release(n, last); release(n, cvec);
+        vh_precond_out_args po{}; po.x = ptr(n, pr.x); po.row_mul = rm; po.f = ptr(n, F); po.fc = F.c; po.sigma = ptr(n, pr.sigma); po.sigma_data = cfg.sigma_data;
+        po.rows = B; po.c = cfg.img_channels; po.h = R; po.w = R; po.out = ptr(n, pr.D);
+        call(n, vh_precond_out, po);
+        release(n, F);
+    }
+    release(n, dgrid);
+}
+
+int check_config(const vh_net_config& c) {
+    VH_REQUIRE(c.img_resolution > 0 && c.img_channels == 3, "vh_net: img_channels must be 3 (UNet out_conv is hard-wired to 3, training/models.py:480)");
+    VH_REQUIRE(c.num_levels >= 1 && c.num_levels <= 8 && c.num_blocks >= 1 && c.model_channels > 0, "vh_net: bad architecture");
+    VH_REQUIRE(c.num_attn_resolutions >= 0 && c.num_attn_resolutions <= 8, "vh_net: bad attn_resolutions");
+    VH_REQUIRE((c.img_resolution >> (c.num_levels - 1)) >= 1 && c.img_resolution % (1 << (c.num_levels - 1)) == 0, "vh_net: resolution not divisible by the level count");
+    VH_REQUIRE(c.source_label_dim > 0 && c.target_label_dim >= 0 && c.logvar_channels > 0, "vh_net: bad label dims");
+    for (int i = 0; i < c.num_levels; ++i)
+        VH_REQUIRE((c.model_channels * c.channel_mult[i]) % 32 == 0, "vh_net: the bf16x3 path needs channel counts that are multiples of 32 (level %d has %d)", i, c.model_channels * c.channel_mult[i]);
+    return VH_OK;
+}
+
+int prep_one(vh_net* n, const std::string& key, int taps, float*& cursor, const float* gain_ptr, int nj, int D) {
+    const Param& p = n->params[n->pindex.at(key)];
+    VH_REQUIRE(p.ptr, "vh_net_prepare: parameter %s is not bound", key.c_str());
+    const int cout = p.shape[0], cin = p.shape[1];
+    const bool conv4 = p.ndim == 4;
+    Weight w; w.cout = cout; w.taps = taps; w.cin_pad = round_up(cin, conv4 ? 32 : 4); w.k_pad = round_up(taps * w.cin_pad, 32); w.wt = cursor;
+    cursor += (size_t)w.k_pad / 4 * cout * 4;
+    const float* src = p.ptr;
+    float* tmp = nullptr;
+    if (nj) {
+        // output channel (head*D + d)*nj + j  ->  (head*nj + j)*D + d (one (head, j) per D-column accumulator slab, VH_EPI_QKV): the rows are
+        // gathered by a device-to-device 2D copy per (head, j) into the tail of the prepared buffer, then normalised from there
+        const int heads = cout / (D * nj);
+        const size_t row = (size_t)cin * taps;
+        tmp = cursor;                                               // scratch behind this weight: overwritten by the next weight's output
+        for (int hh = 0; hh < heads; ++hh)
+            for (int j = 0; j < nj; ++j) {
+                const hipError_t e = hipMemcpy2DAsync(tmp + ((size_t)(hh * nj + j) * D) * row, row * 4, src + ((size_t)hh * D * nj + j) * row, row * 4 * nj, row * 4, D,
+                                                      hipMemcpyDeviceToDevice, n->ctx->stream);
+                if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_net_prepare: %s", hipGetErrorString(e));
+            }
+        src = tmp;
+    }
+    vh_prep_weight_args a{};
+    a.w = src; a.cout = cout; a.cin = cin; a.taps = taps; a.cin_pad = w.cin_pad; a.k_pad = w.k_pad; a.gain_ptr = gain_ptr; a.gain_value = 1.f;
+    a.wt = w.wt; a.dst_col0 = 0; a.dst_cols = cout; a.split = conv4 ? 2 : 0;
+    const int rc = vh_prep_weight(n->ctx, &a);
+    if (rc != VH_OK) return rc;
+    n->W[key] = w;
+    return VH_OK;
+}
+
+size_t prepared_floats(const vh_net* n) {
+    size_t tot = ZEROS_FLOATS + 2 * SCRATCH_FLOATS, biggest = 0;
+    for (const Param& p : n->params) {
+        const std::string& k = p.name;
+        if (k.size() < 6 || k.compare(k.size() - 6, 6, "weight") != 0) continue;
+        if (k.find("emb_linear") != std::string::npos) continue;
+        const int taps = (p.ndim == 4 && p.shape[3] == 3) ? 9 : 1;
+        const int cin_pad = round_up(p.shape[1], p.ndim == 4 ? 32 : 4), k_pad = round_up(taps * cin_pad, 32);
+        tot += (size_t)k_pad / 4 * p.shape[0] * 4;
+        biggest = std::max(biggest, (size_t)p.shape[0] * p.shape[1] * taps);
+    }
+    for (const Spec* sp : {n->has_enc ? &n->enc : (const Spec*)nullptr, &n->unet}) {
+        if (!sp) continue;
+        int total = 0;
+        for (int g = 0; g < 2; ++g) for (const Block& b : (g ? sp->dec : sp->enc)) if (b.live && !b.conv) total += b.cout;
+        tot += (size_t)round_up(sp->cemb, 32) / 4 * total * 4;
+    }
+    return tot + biggest + 64;       // + room for one permuted q/k/v weight behind the last prepared one
+}
+
+}  // namespace
+
+extern "C" int vh_net_create(vh_ctx* ctx, const vh_net_config* cfg, vh_net** out) {
+    if (!ctx || !cfg || !out) return vh_fail(VH_EINVAL, "vh_net_create: null argument");
+    const int rc = check_config(*cfg);
+    if (rc != VH_OK) return rc;
+    auto n = std::make_unique<vh_net>();
+    n->ctx = ctx; n->cfg = *cfg; n->has_enc = !cfg->uncond;
+    if (n->has_enc) { n->enc = make_spec(*cfg, true); spec_params(n->enc, "encoder.", false, n->params); }
+    n->unet = make_spec(*cfg, false); spec_params(n->unet, "unet.", true, n->params);
+    auto add = [&](const char* name, std::initializer_list<int> shp) {
+        Param p; p.name = name; p.ndim = (int)shp.size(); int i = 0; for (int v : shp) p.shape[i++] = v; for (; i < 4; ++i) p.shape[i] = 1; n->params.push_back(p);
+    };
+    add("logvar_fourier.freqs", {cfg->logvar_channels}); add("logvar_fourier.phases", {cfg->logvar_channels}); add("logvar_linear.weight", {1, cfg->logvar_channels});
+    for (size_t i = 0; i < n->params.size(); ++i) n->pindex[n->params[i].name] = (int)i;
+    for (const Spec* sp : {n->has_enc ? &n->enc : (const Spec*)nullptr, &n->unet}) {
+        if (!sp) continue;
+        for (int g = 0; g < 2; ++g)
+            for (const Block& b : (g ? sp->dec : sp->enc))
+                if (b.live && b.heads) {
+                    const int D = b.cout / b.heads;
+                    if ((D != 32 && D != 64) || (b.res * b.res) % 32) return vh_fail(VH_EINVAL, "vh_net: attention block %s needs 32- or 64-channel heads and 32 | res^2", b.name.c_str());
+                }
+    }
+    *out = n.release();
+    return VH_OK;
+}
+
+extern "C" int vh_net_num_params(const vh_net* n) { return n ? (int)n->params.size() : 0; }
+
+extern "C" int vh_net_param_info(const vh_net* n, int i, const char** name, int* ndim, int* shape) {
+    if (!n || i < 0 || i >= (int)n->params.size() || !name || !ndim || !shape) return vh_fail(VH_EINVAL, "vh_net_param_info: bad argument");
+    *name = n->params[i].name.c_str(); *ndim = n->params[i].ndim;
+    for (int k = 0; k < 4; ++k) shape[k] = n->params[i].shape[k];
+    return VH_OK;
+}
+
+extern "C" int vh_net_bind_param(vh_net* n, const char* name, const float* device_ptr) {
+    if (!n || !name || !device_ptr) return vh_fail(VH_EINVAL, "vh_net_bind_param: null argument");
+    auto it = n->pindex.find(name);
+    if (it == n->pindex.end()) return vh_fail(VH_EINVAL, "vh_net_bind_param: no parameter named %s", name);
+    if (!vh_aligned16(device_ptr) && n->params[it->second].ndim >= 2) return vh_fail(VH_EINVAL, "vh_net_bind_param: %s must be 16-byte aligned", name);
+    n->params[it->second].ptr = device_ptr;
+    n->prepared = false;
+    return VH_OK;
+}
+
+extern "C" size_t vh_net_prepared_bytes(const vh_net* n) { return n ? prepared_floats(n) * 4 : 0; }
+
+// K1 once per weight version (the reference re-normalises every weight on every forward, training/models.py:115-120)
+extern "C" int vh_net_prepare(vh_net* n, void* buffer, size_t bytes) {
+    if (!n || !buffer) return vh_fail(VH_EINVAL, "vh_net_prepare: null argument");
+    VH_REQUIRE(bytes >= vh_net_prepared_bytes(n) && vh_aligned16(buffer), "vh_net_prepare: buffer too small (%zu < %zu bytes) or unaligned", bytes, vh_net_prepared_bytes(n));
+    VH_REQUIRE(!n->ctx->recording, "vh_net_prepare: context is recording");
+    for (const Param& p : n->params) VH_REQUIRE(p.ptr, "vh_net_prepare: parameter %s is not bound", p.name.c_str());
+    n->W.clear(); n->programs.clear();
+    float* cur = static_cast<float*>(buffer);
+    hipError_t e = hipMemsetAsync(cur, 0, ZEROS_FLOATS * 4, n->ctx->stream);
+    if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_net_prepare: %s", hipGetErrorString(e));
+    n->zeros = cur; cur += ZEROS_FLOATS;
+    n->scratch_enc = cur; cur += SCRATCH_FLOATS;
+    n->scratch_unet = cur; cur += SCRATCH_FLOATS;
+    for (int which = 0; which < 2; ++which) {
+        if (which == 0 && !n->has_enc) continue;
+        const Spec& sp = which == 0 ? n->enc : n->unet;
+        const std::string prefix = which == 0 ? "encoder." : "unet.";
+        vh_net::EmbW& emb = which == 0 ? n->embE : n->embU;
+        int rc = prep_one(n, prefix + "emb_noise.weight", 1, cur, nullptr, 0, 0);
+        if (rc != VH_OK) return rc;
+        if (sp.label_dim) { rc = prep_one(n, prefix + "emb_label.weight", 1, cur, nullptr, 0, 0); if (rc != VH_OK) return rc; }
+        emb.cols.clear(); emb.total = 0;
+        for (int g = 0; g < 2; ++g) for (const Block& b : (g ? sp.dec : sp.enc)) if (b.live && !b.conv) emb.total += b.cout;
+        const int kpad = round_up(sp.cemb, 32);
+        emb.wt = cur; cur += (size_t)kpad / 4 * emb.total * 4;
+        e = hipMemsetAsync(emb.wt, 0, (size_t)kpad / 4 * emb.total * 16, n->ctx->stream);
+        if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_net_prepare: %s", hipGetErrorString(e));
+        int c0 = 0;
+        for (int g = 0; g < 2; ++g)
+            for (const Block& b : (g ? sp.dec : sp.enc)) {
+                if (!b.live) continue;
+                const std::string p = prefix + (g ? "dec." : "enc.") + b.name + ".";
+                if (b.conv) { rc = prep_one(n, p + "weight", 9, cur, nullptr, 0, 0); if (rc != VH_OK) return rc; continue; }
+                if ((rc = prep_one(n, p + "conv_res0.weight", 9, cur, nullptr, 0, 0)) != VH_OK) return rc;
+                if ((rc = prep_one(n, p + "conv_res1.weight", 9, cur, nullptr, 0, 0)) != VH_OK) return rc;
+                if (b.cin != b.cout && (rc = prep_one(n, p + "conv_skip.weight", 1, cur, nullptr, 0, 0)) != VH_OK) return rc;
+                if (b.heads) {
+                    const int D = b.cout / b.heads;
+                    if ((rc = prep_one(n, p + "attn_qkv.weight", 1, cur, nullptr, 3, D)) != VH_OK) return rc;
+                    if ((rc = prep_one(n, p + "attn_proj.weight", 1, cur, nullptr, 0, 0)) != VH_OK) return rc;
+                    if (b.xattn && (rc = prep_one(n, p + "x_attn_kv.weight", 1, cur, nullptr, 2, D)) != VH_OK) return rc;
+                }
+                vh_prep_weight_args a{};
+                a.w = P(n, p + "emb_linear.weight"); a.cout = b.cout; a.cin = sp.cemb; a.taps = 1; a.cin_pad = round_up(sp.cemb, 4); a.k_pad = kpad;
+                a.gain_ptr = P(n, p + "emb_gain"); a.gain_value = 1.f; a.wt = emb.wt; a.dst_col0 = c0; a.dst_cols = emb.total; a.split = 0;
+                if ((rc = vh_prep_weight(n->ctx, &a)) != VH_OK) return rc;
+                emb.cols[p] = c0; c0 += b.cout;
+            }
+        if (sp.out_channels && (rc = prep_one(n, prefix + "out_conv.weight", 9, cur, P(n, prefix + "out_gain"), 0, 0)) != VH_OK) return rc;
+    }
+    n->prepared = true;
+    return VH_OK;
+}
+
+static int net_build(vh_net* n, int B, float* workspace, size_t bytes, Program** out) {
+    VH_REQUIRE(n->prepared, "vh_net: call vh_net_prepare after binding the parameters");
+    VH_REQUIRE(B > 0, "vh_net: batch must be positive");
+    auto pr = std::make_unique<Program>();
+    pr->B = B;
+    Arena dry;
+    n->A = &dry; n->base = nullptr; n->emit = false; n->rc = VH_OK;
+    walk(n, B, *pr);
+    n->A = nullptr;
+    if (n->rc != VH_OK) return n->rc;
+    pr->peak_floats = dry.peak;
+    if (!workspace) { *out = pr.release(); return VH_OK; }
+    VH_REQUIRE(bytes >= (size_t)dry.peak * 4 && vh_aligned16(workspace), "vh_net_record: workspace too small (%zu < %lld bytes) or unaligned", bytes, dry.peak * 4LL);
+    Arena real;
+    Program rec; rec.B = B;
+    int rc = vh_plan_begin(n->ctx);
+    if (rc != VH_OK) return rc;
+    n->A = &real; n->base = workspace; n->emit = true; n->rc = VH_OK;
+    walk(n, B, rec);
+    n->A = nullptr; n->emit = false;
+    if (n->rc != VH_OK) { (void)vh_plan_abort(n->ctx); return n->rc; }
+    rc = vh_plan_end(n->ctx, &rec.plan);
+    if (rc != VH_OK) return rc;
+    rec.base = workspace; rec.peak_floats = real.peak;
+    *pr = rec;
+    *out = pr.release();
+    return VH_OK;
+}
+
+extern "C" size_t vh_net_workspace_bytes(vh_net* n, int batch) {
+    if (!n) return 0;
+    Program* p = nullptr;
+    if (net_build(n, batch, nullptr, 0, &p) != VH_OK) return 0;
+    const size_t b = (size_t)p->peak_floats * 4;
+    delete p;
+    return b;
+}
+
+extern "C" int vh_net_record(vh_net* n, int batch, void* workspace, size_t bytes) {
+    if (!n || !workspace) return vh_fail(VH_EINVAL, "vh_net_record: null argument");
+    Program* p = nullptr;
+    const int rc = net_build(n, batch, static_cast<float*>(workspace), bytes, &p);
+    if (rc != VH_OK) return rc;
+    auto it = n->programs.find(batch);
+    if (it != n->programs.end() && it->second->plan) (void)vh_plan_destroy(it->second->plan);
+    n->programs[batch].reset(p);
+    return VH_OK;
+}
+
+// One evaluation: D = net(src, x, sigma, geometry, cond).  All pointers are device fp32, contiguous, in the reference's layouts:
+// src [rows][3 or 4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim] (NULL for an uncond net: zeros),
+// cond [B][3][R][R] (super_res only), out [B][3][R][R]; rows = B * (dual_source ? 2 : 1).
+extern "C" int vh_net_run(vh_net* n, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+    if (!n || !x || !sigma || !out) return vh_fail(VH_EINVAL, "vh_net_run: null argument");
+    auto it = n->programs.find(batch);
+    VH_REQUIRE(it != n->programs.end() && it->second->plan, "vh_net_run: no program recorded for batch %d (vh_net_record)", batch);
+    Program& p = *it->second;
+    hipStream_t s = n->ctx->stream;
+    auto put = [&](const Buf& b, const float* from) -> int {
+        if (!b.ok()) return VH_OK;
+        hipError_t e = from ? hipMemcpyAsync(p.base + b.off, from, (size_t)b.n * 4, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(p.base + b.off, 0, (size_t)b.n * 4, s);
+        return e == hipSuccess ? VH_OK : vh_fail(VH_EHIP, "vh_net_run: %s", hipGetErrorString(e));
+    };
+    VH_REQUIRE(!p.src.ok() || src, "vh_net_run: this net reads src");
+    VH_REQUIRE(!p.cond.ok() || cond, "vh_net_run: a super_res net needs the conditioning image (training/models.py:656)");
+    VH_REQUIRE(geometry || n->cfg.uncond, "vh_net_run: geometry is required for a conditional net (training/models.py:631)");
+    int rc;
+    if ((rc = put(p.sigma, sigma)) != VH_OK || (rc = put(p.geometry, geometry)) != VH_OK || (rc = put(p.src, src)) != VH_OK ||
+        (rc = put(p.x, x)) != VH_OK || (rc = put(p.cond, cond)) != VH_OK) return rc;
+    if ((rc = vh_plan_run(n->ctx, p.plan)) != VH_OK) return rc;
+    const hipError_t e = hipMemcpyAsync(out, p.base + p.D.off, (size_t)p.D.n * 4, hipMemcpyDeviceToDevice, s);
+    return e == hipSuccess ? VH_OK : vh_fail(VH_EHIP, "vh_net_run: %s", hipGetErrorString(e));
+}
+
+extern "C" int vh_net_destroy(vh_net* n) {
+    if (!n) return VH_OK;
+    for (auto& kv : n->programs) if (kv.second && kv.second->plan) (void)vh_plan_destroy(kv.second->plan);
+    delete n;
+    return VH_OK;
+}
