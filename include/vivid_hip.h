@@ -428,6 +428,59 @@ typedef struct {
 } vh_psnr_args;
 int vh_psnr_sum(vh_ctx* ctx, const vh_psnr_args* a);
 
+/* ---- whole-network evaluation ---------------------------------------------------------------------------------
+ * One NVPrecond evaluation, D_x = net(src, x, sigma, geometry, cond), as ONE call: NVPrecond._forward_dualsource
+ * training/models.py:628-689 (dual_source = 1) / NVPrecond.forward :691-749 (dual_source = 0), i.e. EDM preconditioning :633-639, the
+ * optional depth-warp / super-resolution input assembly :643-661, UNetEncoder.forward :536-570 on the source rows, XAttnUNet.forward
+ * :483-518 on the target rows, D_x :683 - for hosts that do not run Python (last row).  The library generates the
+ * architecture from the constructor arguments (UNet.__init__ :322-384, XAttnUNet :413-480, UNetEncoder trimming :524-534,
+ * SRXAttnUNet :576-582), names the parameters with the reference's state_dict keys, prepares the weights once (:115-120) and
+ * records the evaluation per batch size as a vh_plan over a workspace the caller owns; a call copies the inputs in, replays, and
+ * copies D_x out - no allocation, no host synchronisation.  Arithmetic: bf16x3 (see VH_PREC_BF16X3) on the direct-to-LDS kernels;
+ * channel counts must be multiples of 32, attention heads 64 (32 for super_res UNets) channels, resample_filter [1,1].
+ * An `uncond` net has no encoder: the zero features of :727-736 enter the attention in closed form and `src` / `geometry` may be NULL.
+ * vivid_amd.NVPrecond (engine.py) emits the same op sequence from Python; tests/test_hip_net_c.py compares the two bit for bit.
+ *
+ *   vh_net_create(ctx, &cfg, &net);
+ *   for i < vh_net_num_params(net): vh_net_param_info(net, i, &name, &ndim, shape); vh_net_bind_param(net, name, device_fp32_ptr);
+ *   vh_net_prepare(net, buf, vh_net_prepared_bytes(net));                 // again after the weights change
+ *   vh_net_record(net, B, workspace, vh_net_workspace_bytes(net, B));     // once per batch size
+ *   vh_net_run(net, B, src, x, sigma, geometry, cond, out);               // any number of times, on the context's stream
+ */
+typedef struct vh_net vh_net;
+typedef struct {
+    int img_resolution, img_channels;          /* img_channels must be 3 (:480) */
+    int source_label_dim, target_label_dim;    /* 20 / 40 in the reference's presets (train_nvs.py) */
+    int model_channels;                        /* 128 (vivid-base), 64 (vivid-sr) */
+    int channel_mult[8]; int num_levels;       /* 1,2,3,4 and 4 */
+    int num_blocks;                            /* 3 */
+    int attn_resolutions[8]; int num_attn_resolutions;   /* 16, 8 and 2 - absolute resolutions (:331) */
+    int extra_attn;                            /* block index that also gets attention at every level but the first, -1 = none (:366) */
+    int channel_mult_noise, channel_mult_emb;  /* 0 = the reference's None (:340-341) */
+    double label_balance, concat_balance, res_balance, attn_balance;  /* 0.5, 0.5, 0.3, 0.3 (double: the mp_sum / mp_cat coefficients are derived
+                                                                          from them in double, like the reference's Python floats, :72-84) */
+    double clip_act;                           /* 256; <= 0 = None */
+    double sigma_data;                         /* 0.5 */
+    int logvar_channels;                       /* 128 */
+    int super_res, no_time_enc, depth_input, warp_depth_coor, uncond;
+    int dual_source;                           /* 1: the HEAD forward (two source rows per target), 0: the single-source forward */
+    float geom_mean[20], geom_std[20];         /* warp_depth_coor only: the geometry statistics for this image size (training/utils.py:38-44, 77-78) */
+} vh_net_config;
+int vh_net_create(vh_ctx* ctx, const vh_net_config* cfg, vh_net** out);
+int vh_net_destroy(vh_net* net);
+int vh_net_num_params(const vh_net* net);
+/* name: a state_dict key of the reference's NVPrecond; shape: up to 4 dims (OIHW for convolutions), unused dims 1; 0-d gains have ndim 0 */
+int vh_net_param_info(const vh_net* net, int i, const char** name, int* ndim, int* shape);
+int vh_net_bind_param(vh_net* net, const char* name, const float* device_ptr);   /* contiguous fp32, stays owned by the caller */
+size_t vh_net_prepared_bytes(const vh_net* net);
+int vh_net_prepare(vh_net* net, void* buffer, size_t bytes);                     /* normalised / re-laid-out weights live in `buffer` */
+size_t vh_net_workspace_bytes(vh_net* net, int batch);                           /* 0 on error (see vh_last_error) */
+int vh_net_record(vh_net* net, int batch, void* workspace, size_t bytes);
+/* src [rows][3|4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim], cond [batch][3][R][R] (super_res),
+ * out [batch][3][R][R]; rows = batch * (dual_source ? 2 : 1); device fp32, contiguous.  Odd rows of x / sigma are ignored in
+ * dual-source mode, like the reference (:676-678). */
+int vh_net_run(vh_net* net, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out);
+
 #ifdef __cplusplus
 }
 #endif

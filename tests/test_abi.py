@@ -17,9 +17,9 @@ def _header():
 
 def test_library_exports_every_declared_symbol():
     L = _lib.lib()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(vh_\w+)\s*\(", _header(), flags=re.M))
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(vh_\w+)\s*\(", _header(), flags=re.M))
     assert declared, "no declarations found in the header"
-    assert declared == set(_lib.OPS) | set(_lib.CONTROL)
+    assert declared == set(_lib.OPS) | set(_lib.CONTROL) | set(_lib.NET)
     for name in declared:
         assert hasattr(L, name), name
     assert L.vh_abi_version() == _lib.ABI_VERSION
@@ -33,7 +33,7 @@ def test_struct_mirrors_match_header_field_counts():
              "vh_precond_out_args": _lib.PrecondOutArgs, "vh_warp_args": _lib.WarpArgs,
              "vh_sampler_step_args": _lib.SamplerStepArgs, "vh_qkv_epilogue": _lib.QkvEpilogue, "vh_codec_args": _lib.CodecArgs, "vh_add_depth_args": _lib.AddDepthArgs, "vh_resize_args": _lib.ResizeArgs,
              "vh_nonzero_args": _lib.NonzeroArgs, "vh_resample_args": _lib.ResampleArgs, "vh_moments_args": _lib.MomentsArgs,
-             "vh_psnr_args": _lib.PsnrArgs}
+             "vh_psnr_args": _lib.PsnrArgs, "vh_net_config": _lib.NetConfigC}
     for cname, st in pairs.items():
         m = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + r"\s*;", h, flags=re.S)
         assert m, cname

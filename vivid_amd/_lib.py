@@ -148,6 +148,18 @@ class SamplerStepArgs(C.Structure):
                 ("rows", C.c_int), ("row_mul", C.c_int), ("row_elems", C.c_size_t), ("x_next", C.c_void_p)]
 
 
+class NetConfigC(C.Structure):
+    """vh_net_config"""
+    _fields_ = [("img_resolution", C.c_int), ("img_channels", C.c_int), ("source_label_dim", C.c_int), ("target_label_dim", C.c_int),
+                ("model_channels", C.c_int), ("channel_mult", C.c_int * 8), ("num_levels", C.c_int), ("num_blocks", C.c_int),
+                ("attn_resolutions", C.c_int * 8), ("num_attn_resolutions", C.c_int), ("extra_attn", C.c_int),
+                ("channel_mult_noise", C.c_int), ("channel_mult_emb", C.c_int),
+                ("label_balance", C.c_double), ("concat_balance", C.c_double), ("res_balance", C.c_double), ("attn_balance", C.c_double),
+                ("clip_act", C.c_double), ("sigma_data", C.c_double), ("logvar_channels", C.c_int),
+                ("super_res", C.c_int), ("no_time_enc", C.c_int), ("depth_input", C.c_int), ("warp_depth_coor", C.c_int), ("uncond", C.c_int),
+                ("dual_source", C.c_int), ("geom_mean", C.c_float * 20), ("geom_std", C.c_float * 20)]
+
+
 # every symbol include/vivid_hip.h declares: name -> (args struct or None)
 OPS = {
     "vh_prep_weight": PrepWeightArgs, "vh_conv": ConvArgs, "vh_pixnorm": PixnormArgs, "vh_split": SplitArgs,
@@ -162,6 +174,9 @@ TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "ass
 CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
            "vh_plan_begin", "vh_plan_end", "vh_plan_abort", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
+
+NET = ["vh_net_create", "vh_net_destroy", "vh_net_num_params", "vh_net_param_info", "vh_net_bind_param", "vh_net_prepared_bytes",
+       "vh_net_prepare", "vh_net_workspace_bytes", "vh_net_record", "vh_net_run"]
 
 _lib = None
 
@@ -205,6 +220,18 @@ def lib():
         fn.restype = C.c_int
     for name in CONTROL:
         getattr(L, name)
+    L.vh_net_create.argtypes = [C.c_void_p, C.POINTER(NetConfigC), C.POINTER(C.c_void_p)]
+    L.vh_net_destroy.argtypes = [C.c_void_p]
+    L.vh_net_num_params.argtypes = [C.c_void_p]
+    L.vh_net_param_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.vh_net_bind_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    L.vh_net_prepared_bytes.argtypes = [C.c_void_p]
+    L.vh_net_prepared_bytes.restype = C.c_size_t
+    L.vh_net_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.vh_net_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
+    L.vh_net_workspace_bytes.restype = C.c_size_t
+    L.vh_net_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.vh_net_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
     _lib = L
     return L
 

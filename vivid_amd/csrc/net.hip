@@ -150,7 +150,7 @@ struct Arena {
 };
 struct Buf { long long off = -1; long long n = 0; int c = 0; bool ok() const { return off >= 0; } };   // n floats; c = channels (last dim)
 
-struct Weight { float* wt = nullptr; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0; };
+struct Weight { float* wt = nullptr; size_t off = 0; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0, nj = 0, D = 0; const float* gain = nullptr; bool has_gain = false; };
 
 struct Program {
     int B = 0;
@@ -171,7 +171,9 @@ struct vh_net {
     std::map<std::string, int> pindex;
     // prepared weights (inside the caller's buffer)
     std::map<std::string, Weight> W;
-    struct EmbW { float* wt = nullptr; std::map<std::string, int> cols; int total = 0; } embE, embU;
+    struct EmbW { float* wt = nullptr; size_t off = 0; std::map<std::string, int> cols; int total = 0; } embE, embU;
+    std::vector<std::string> prep_order;          // keys of W in preparation order
+    size_t prepared_floats = 0;
     float* zeros = nullptr; float* scratch_enc = nullptr; float* scratch_unet = nullptr; float* scratch = nullptr;
     bool prepared = false;
     std::map<int, std::unique_ptr<Program>> programs;
@@ -231,7 +233,7 @@ std::pair<Buf, Buf> split(vh_net* n, const Buf& s0, float sc0, const Buf* s1, fl
     call(n, vh_split, a);
     return {out, raw};
 }
-void mp_sum_coeffs(float t, float& a, float& b) { const double nn = std::sqrt((1.0 - t) * (1.0 - t) + (double)t * t); a = (float)((1.0 - t) / nn); b = (float)(t / nn); }
+void mp_sum_coeffs(double t, float& a, float& b) { const double nn = std::sqrt((1.0 - t) * (1.0 - t) + t * t); a = (float)((1.0 - t) / nn); b = (float)(t / nn); }
 
 struct Feat { Buf f32, s8; };
 
@@ -244,7 +246,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
     const float* cv = ptr(n, cvec_all) ? ptr(n, cvec_all) + emb.cols.at(p) : (const float*)nullptr;
     if (!n->emit) cv = reinterpret_cast<const float*>(16);          // (dry walk: never dereferenced)
     float ta, tb; mp_sum_coeffs(cfg.res_balance, ta, tb);
-    const float clip = cfg.clip_act > 0.f ? cfg.clip_act : 0.f, clip_res = b.heads ? 0.f : clip;
+    const float clip = cfg.clip_act > 0.0 ? (float)cfg.clip_act : 0.f, clip_res = b.heads ? 0.f : clip;
     const bool has_skip_conv = b.cin != b.cout;
     const bool res1_s8 = b.heads > 0, fin_s8 = want_s8 && !b.heads;
     const long long npix = (long long)rows * R * R;
@@ -309,15 +311,32 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         const float nz = (b.xattn && !use_feat) ? n_zero * S : 0.f;
         const int klp = round_up(kl, 64);
         Buf q = alloc(n, rows, b.heads, S, D), k = alloc(n, rows, b.heads, klp, D), v = alloc(n, rows, b.heads, klp, D);
-        vh_qkv_epilogue e{}; e.q = ptr(n, q); e.k = ptr(n, k); e.v = ptr(n, v); e.heads = b.heads; e.nj = 3; e.rows_per_b = 1; e.koff = 0; e.kl = kl;
-        e.qscale = (float)(LOG2E / std::sqrt((double)D));
-        ConvOpt oq; oq.qkv = &e;
-        conv(n, r_s8, n->W.at(p + "attn_qkv.weight"), rows, R, R, oq);
+        const bool fused = S % 32 == 0;
+        const float qscale = (float)(LOG2E / std::sqrt((double)D));
+        if (fused) {
+            vh_qkv_epilogue e{}; e.q = ptr(n, q); e.k = ptr(n, k); e.v = ptr(n, v); e.heads = b.heads; e.nj = 3; e.rows_per_b = 1; e.koff = 0; e.kl = kl; e.qscale = qscale;
+            ConvOpt oq; oq.qkv = &e;
+            conv(n, r_s8, n->W.at(p + "attn_qkv.weight"), rows, R, R, oq);
+        } else {
+            Buf qkv = conv(n, r_s8, n->W.at(p + "attn_qkv.weight"), rows, R, R, ConvOpt{}).first;
+            vh_qkv_split_args sa{}; sa.in = ptr(n, qkv); sa.rows = rows; sa.s = S; sa.heads = b.heads; sa.d = D; sa.nj = 3; sa.rows_per_b = 1; sa.koff = 0; sa.kl = kl;
+            sa.qscale = qscale; sa.q = ptr(n, q); sa.k = ptr(n, k); sa.v = ptr(n, v);
+            call(n, vh_qkv_split_x3, sa);
+            release(n, qkv);
+        }
         release(n, r_s8);
         if (use_feat) {
-            vh_qkv_epilogue e2{}; e2.q = nullptr; e2.k = ptr(n, k); e2.v = ptr(n, v); e2.heads = b.heads; e2.nj = 2; e2.rows_per_b = nsrc; e2.koff = S; e2.kl = kl; e2.qscale = 1.f;
-            ConvOpt ok; ok.qkv = &e2;
-            conv(n, feat->s8, n->W.at(p + "x_attn_kv.weight"), rows * nsrc, R, R, ok);
+            if (fused) {
+                vh_qkv_epilogue e2{}; e2.q = nullptr; e2.k = ptr(n, k); e2.v = ptr(n, v); e2.heads = b.heads; e2.nj = 2; e2.rows_per_b = nsrc; e2.koff = S; e2.kl = kl; e2.qscale = 1.f;
+                ConvOpt ok; ok.qkv = &e2;
+                conv(n, feat->s8, n->W.at(p + "x_attn_kv.weight"), rows * nsrc, R, R, ok);
+            } else {
+                Buf kv = conv(n, feat->s8, n->W.at(p + "x_attn_kv.weight"), rows * nsrc, R, R, ConvOpt{}).first;
+                vh_qkv_split_args sa{}; sa.in = ptr(n, kv); sa.rows = rows * nsrc; sa.s = S; sa.heads = b.heads; sa.d = D; sa.nj = 2; sa.rows_per_b = nsrc; sa.koff = S; sa.kl = kl;
+                sa.qscale = 1.f; sa.q = nullptr; sa.k = ptr(n, k); sa.v = ptr(n, v);
+                call(n, vh_qkv_split_x3, sa);
+                release(n, kv);
+            }
         }
         Buf att = alloc(n, rows, R, R, C);
         vh_attention_args aa{}; aa.q = ptr(n, q); aa.k = ptr(n, k); aa.v = ptr(n, v); aa.b = rows; aa.heads = b.heads; aa.s = S; aa.kl = kl; aa.d = D;
@@ -346,7 +365,7 @@ Buf embedding(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net
     a.freqs = P(n, prefix + "emb_fourier.freqs"); a.phases = P(n, prefix + "emb_fourier.phases"); a.cnoise = sp.cnoise;
     a.w_noise = wn.wt; a.w_noise_kpad = wn.k_pad;
     if (has_label) { const Weight& wl = n->W.at(prefix + "emb_label.weight"); a.w_label = wl.wt; a.w_label_kpad = wl.k_pad; }
-    a.label_balance = cfg.label_balance; a.rows = rows; a.cemb = sp.cemb; a.raw = 0; a.emb = ptr(n, e);
+    a.label_balance = (float)cfg.label_balance; a.rows = rows; a.cemb = sp.cemb; a.raw = 0; a.emb = ptr(n, e);
     call(n, vh_embed, a);
     Buf cvec = alloc(n, rows, 1, 1, emb.total);
     vh_linear_args l{}; l.emb = ptr(n, e); l.rows = rows; l.cemb = sp.cemb; l.wt = emb.wt; l.k_pad = round_up(sp.cemb, 32); l.cols = emb.total; l.bias = 1.f; l.out = ptr(n, cvec);
@@ -403,7 +422,7 @@ Buf assemble(vh_net* n, const vh_segment* segs, int nseg, int rows, int R, int c
     Buf out = alloc(n, rows, R, R, c_pad);
     vh_assemble_args a{};
     a.nseg = nseg; for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
-    a.sigma = ptr(n, sigma); a.sigma_data = n->cfg.sigma_data; a.rows = rows; a.h = R; a.w = R; a.c_pad = c_pad; a.out = ptr(n, out);
+    a.sigma = ptr(n, sigma); a.sigma_data = (float)n->cfg.sigma_data; a.rows = rows; a.h = R; a.w = R; a.c_pad = c_pad; a.out = ptr(n, out);
     call(n, vh_assemble, a);
     return out;
 }
@@ -462,7 +481,7 @@ void walk(vh_net* n, int B, Program& pr) {
         auto ls8 = split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false);
         Buf F = conv(n, ls8.first, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
         release(n, ls8.first); release(n, last); release(n, cvec);
-        vh_precond_out_args po{}; po.x = ptr(n, pr.x); po.row_mul = rm; po.f = ptr(n, F); po.fc = F.c; po.sigma = ptr(n, pr.sigma); po.sigma_data = cfg.sigma_data;
+        vh_precond_out_args po{}; po.x = ptr(n, pr.x); po.row_mul = rm; po.f = ptr(n, F); po.fc = F.c; po.sigma = ptr(n, pr.sigma); po.sigma_data = (float)cfg.sigma_data;
         po.rows = B; po.c = cfg.img_channels; po.h = R; po.w = R; po.out = ptr(n, pr.D);
         call(n, vh_precond_out, po);
         release(n, F);
@@ -481,56 +500,76 @@ int check_config(const vh_net_config& c) {
     return VH_OK;
 }
 
-int prep_one(vh_net* n, const std::string& key, int taps, float*& cursor, const float* gain_ptr, int nj, int D) {
+// Layout of the prepared-weight buffer (offsets in floats), fixed at creation: [zero page][split-K scratch x2] then, per network, the
+// embedding matrices and every convolution weight in walk order; a permuted copy of one q/k/v weight fits behind the last one.
+void layout(vh_net* n) {
+    size_t cur = ZEROS_FLOATS + 2 * SCRATCH_FLOATS, biggest = 0;
+    auto add = [&](const std::string& key, int taps, int nj, int D, bool has_gain) {
+        const Param& p = n->params[n->pindex.at(key)];
+        const bool conv4 = p.ndim == 4;
+        Weight w; w.cout = p.shape[0]; w.taps = taps; w.cin_pad = round_up(p.shape[1], conv4 ? 32 : 4); w.k_pad = round_up(taps * w.cin_pad, 32);
+        w.off = cur; w.nj = nj; w.D = D; w.has_gain = has_gain;
+        cur += (size_t)w.k_pad / 4 * w.cout * 4;
+        if (nj) biggest = std::max(biggest, (size_t)p.shape[0] * p.shape[1] * taps);
+        n->W[key] = w;
+        n->prep_order.push_back(key);
+    };
+    for (int which = 0; which < 2; ++which) {
+        if (which == 0 && !n->has_enc) continue;
+        const Spec& sp = which == 0 ? n->enc : n->unet;
+        const std::string prefix = which == 0 ? "encoder." : "unet.";
+        vh_net::EmbW& emb = which == 0 ? n->embE : n->embU;
+        add(prefix + "emb_noise.weight", 1, 0, 0, false);
+        if (sp.label_dim) add(prefix + "emb_label.weight", 1, 0, 0, false);
+        emb.total = 0;
+        for (int g = 0; g < 2; ++g) for (const Block& b : (g ? sp.dec : sp.enc)) if (b.live && !b.conv) { emb.cols[prefix + (g ? "dec." : "enc.") + b.name + "."] = emb.total; emb.total += b.cout; }
+        emb.off = cur; cur += (size_t)round_up(sp.cemb, 32) / 4 * emb.total * 4;
+        for (int g = 0; g < 2; ++g)
+            for (const Block& b : (g ? sp.dec : sp.enc)) {
+                if (!b.live) continue;
+                const std::string p = prefix + (g ? "dec." : "enc.") + b.name + ".";
+                if (b.conv) { add(p + "weight", 9, 0, 0, false); continue; }
+                add(p + "conv_res0.weight", 9, 0, 0, false);
+                add(p + "conv_res1.weight", 9, 0, 0, false);
+                if (b.cin != b.cout) add(p + "conv_skip.weight", 1, 0, 0, false);
+                if (b.heads) {
+                    const int D = b.cout / b.heads;
+                    const bool fused = (b.res * b.res) % 32 == 0;      // VH_EPI_QKV needs 32 | pixels per image; else vh_qkv_split_x3 on an fp32 tensor
+                    add(p + "attn_qkv.weight", 1, fused ? 3 : 0, D, false);
+                    add(p + "attn_proj.weight", 1, 0, 0, false);
+                    if (b.xattn) add(p + "x_attn_kv.weight", 1, fused ? 2 : 0, D, false);
+                }
+            }
+        if (sp.out_channels) add(prefix + "out_conv.weight", 9, 0, 0, true);
+    }
+    n->prepared_floats = cur + biggest + 64;
+}
+
+int prep_one(vh_net* n, const std::string& key, float* base) {
+    Weight& w = n->W.at(key);
     const Param& p = n->params[n->pindex.at(key)];
-    VH_REQUIRE(p.ptr, "vh_net_prepare: parameter %s is not bound", key.c_str());
+    w.wt = base + w.off;
     const int cout = p.shape[0], cin = p.shape[1];
-    const bool conv4 = p.ndim == 4;
-    Weight w; w.cout = cout; w.taps = taps; w.cin_pad = round_up(cin, conv4 ? 32 : 4); w.k_pad = round_up(taps * w.cin_pad, 32); w.wt = cursor;
-    cursor += (size_t)w.k_pad / 4 * cout * 4;
     const float* src = p.ptr;
-    float* tmp = nullptr;
-    if (nj) {
+    if (w.nj) {
         // output channel (head*D + d)*nj + j  ->  (head*nj + j)*D + d (one (head, j) per D-column accumulator slab, VH_EPI_QKV): the rows are
-        // gathered by a device-to-device 2D copy per (head, j) into the tail of the prepared buffer, then normalised from there
-        const int heads = cout / (D * nj);
-        const size_t row = (size_t)cin * taps;
-        tmp = cursor;                                               // scratch behind this weight: overwritten by the next weight's output
+        // gathered by one strided device-to-device copy per (head, j) into the space behind this weight's output, then normalised from there
+        const int heads = cout / (w.D * w.nj);
+        const size_t row = (size_t)cin * w.taps;
+        float* tmp = w.wt + (size_t)w.k_pad / 4 * cout * 4;
         for (int hh = 0; hh < heads; ++hh)
-            for (int j = 0; j < nj; ++j) {
-                const hipError_t e = hipMemcpy2DAsync(tmp + ((size_t)(hh * nj + j) * D) * row, row * 4, src + ((size_t)hh * D * nj + j) * row, row * 4 * nj, row * 4, D,
-                                                      hipMemcpyDeviceToDevice, n->ctx->stream);
+            for (int j = 0; j < w.nj; ++j) {
+                const hipError_t e = hipMemcpy2DAsync(tmp + ((size_t)(hh * w.nj + j) * w.D) * row, row * 4, src + ((size_t)hh * w.D * w.nj + j) * row, row * 4 * w.nj,
+                                                      row * 4, w.D, hipMemcpyDeviceToDevice, n->ctx->stream);
                 if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_net_prepare: %s", hipGetErrorString(e));
             }
         src = tmp;
     }
     vh_prep_weight_args a{};
-    a.w = src; a.cout = cout; a.cin = cin; a.taps = taps; a.cin_pad = w.cin_pad; a.k_pad = w.k_pad; a.gain_ptr = gain_ptr; a.gain_value = 1.f;
-    a.wt = w.wt; a.dst_col0 = 0; a.dst_cols = cout; a.split = conv4 ? 2 : 0;
-    const int rc = vh_prep_weight(n->ctx, &a);
-    if (rc != VH_OK) return rc;
-    n->W[key] = w;
-    return VH_OK;
-}
-
-size_t prepared_floats(const vh_net* n) {
-    size_t tot = ZEROS_FLOATS + 2 * SCRATCH_FLOATS, biggest = 0;
-    for (const Param& p : n->params) {
-        const std::string& k = p.name;
-        if (k.size() < 6 || k.compare(k.size() - 6, 6, "weight") != 0) continue;
-        if (k.find("emb_linear") != std::string::npos) continue;
-        const int taps = (p.ndim == 4 && p.shape[3] == 3) ? 9 : 1;
-        const int cin_pad = round_up(p.shape[1], p.ndim == 4 ? 32 : 4), k_pad = round_up(taps * cin_pad, 32);
-        tot += (size_t)k_pad / 4 * p.shape[0] * 4;
-        biggest = std::max(biggest, (size_t)p.shape[0] * p.shape[1] * taps);
-    }
-    for (const Spec* sp : {n->has_enc ? &n->enc : (const Spec*)nullptr, &n->unet}) {
-        if (!sp) continue;
-        int total = 0;
-        for (int g = 0; g < 2; ++g) for (const Block& b : (g ? sp->dec : sp->enc)) if (b.live && !b.conv) total += b.cout;
-        tot += (size_t)round_up(sp->cemb, 32) / 4 * total * 4;
-    }
-    return tot + biggest + 64;       // + room for one permuted q/k/v weight behind the last prepared one
+    a.w = src; a.cout = cout; a.cin = cin; a.taps = w.taps; a.cin_pad = w.cin_pad; a.k_pad = w.k_pad;
+    a.gain_ptr = w.has_gain ? P(n, key.substr(0, key.size() - std::string("out_conv.weight").size()) + "out_gain") : nullptr; a.gain_value = 1.f;
+    a.wt = w.wt; a.dst_col0 = 0; a.dst_cols = cout; a.split = p.ndim == 4 ? 2 : 0;
+    return vh_prep_weight(n->ctx, &a);
 }
 
 }  // namespace
@@ -548,15 +587,16 @@ extern "C" int vh_net_create(vh_ctx* ctx, const vh_net_config* cfg, vh_net** out
     };
     add("logvar_fourier.freqs", {cfg->logvar_channels}); add("logvar_fourier.phases", {cfg->logvar_channels}); add("logvar_linear.weight", {1, cfg->logvar_channels});
     for (size_t i = 0; i < n->params.size(); ++i) n->pindex[n->params[i].name] = (int)i;
-    for (const Spec* sp : {n->has_enc ? &n->enc : (const Spec*)nullptr, &n->unet}) {
+    for (const Spec* sp : {n->has_enc ? (const Spec*)&n->enc : (const Spec*)nullptr, (const Spec*)&n->unet}) {
         if (!sp) continue;
         for (int g = 0; g < 2; ++g)
             for (const Block& b : (g ? sp->dec : sp->enc))
                 if (b.live && b.heads) {
                     const int D = b.cout / b.heads;
-                    if ((D != 32 && D != 64) || (b.res * b.res) % 32) return vh_fail(VH_EINVAL, "vh_net: attention block %s needs 32- or 64-channel heads and 32 | res^2", b.name.c_str());
+                    if (D != 32 && D != 64) return vh_fail(VH_EINVAL, "vh_net: attention block %s needs 32- or 64-channel heads", b.name.c_str());
                 }
     }
+    layout(n.get());
     *out = n.release();
     return VH_OK;
 }
@@ -580,7 +620,7 @@ extern "C" int vh_net_bind_param(vh_net* n, const char* name, const float* devic
     return VH_OK;
 }
 
-extern "C" size_t vh_net_prepared_bytes(const vh_net* n) { return n ? prepared_floats(n) * 4 : 0; }
+extern "C" size_t vh_net_prepared_bytes(const vh_net* n) { return n ? n->prepared_floats * 4 : 0; }
 
 // K1 once per weight version (the reference re-normalises every weight on every forward, training/models.py:115-120)
 extern "C" int vh_net_prepare(vh_net* n, void* buffer, size_t bytes) {
@@ -588,57 +628,40 @@ extern "C" int vh_net_prepare(vh_net* n, void* buffer, size_t bytes) {
     VH_REQUIRE(bytes >= vh_net_prepared_bytes(n) && vh_aligned16(buffer), "vh_net_prepare: buffer too small (%zu < %zu bytes) or unaligned", bytes, vh_net_prepared_bytes(n));
     VH_REQUIRE(!n->ctx->recording, "vh_net_prepare: context is recording");
     for (const Param& p : n->params) VH_REQUIRE(p.ptr, "vh_net_prepare: parameter %s is not bound", p.name.c_str());
-    n->W.clear(); n->programs.clear();
-    float* cur = static_cast<float*>(buffer);
-    hipError_t e = hipMemsetAsync(cur, 0, ZEROS_FLOATS * 4, n->ctx->stream);
+    for (auto& kv : n->programs) if (kv.second && kv.second->plan) (void)vh_plan_destroy(kv.second->plan);
+    n->programs.clear();
+    float* base = static_cast<float*>(buffer);
+    hipError_t e = hipMemsetAsync(base, 0, ZEROS_FLOATS * 4, n->ctx->stream);
     if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_net_prepare: %s", hipGetErrorString(e));
-    n->zeros = cur; cur += ZEROS_FLOATS;
-    n->scratch_enc = cur; cur += SCRATCH_FLOATS;
-    n->scratch_unet = cur; cur += SCRATCH_FLOATS;
+    n->zeros = base; n->scratch_enc = base + ZEROS_FLOATS; n->scratch_unet = n->scratch_enc + SCRATCH_FLOATS;
+    for (const std::string& key : n->prep_order) {
+        const int rc = prep_one(n, key, base);
+        if (rc != VH_OK) return rc;
+    }
     for (int which = 0; which < 2; ++which) {
         if (which == 0 && !n->has_enc) continue;
         const Spec& sp = which == 0 ? n->enc : n->unet;
-        const std::string prefix = which == 0 ? "encoder." : "unet.";
         vh_net::EmbW& emb = which == 0 ? n->embE : n->embU;
-        int rc = prep_one(n, prefix + "emb_noise.weight", 1, cur, nullptr, 0, 0);
-        if (rc != VH_OK) return rc;
-        if (sp.label_dim) { rc = prep_one(n, prefix + "emb_label.weight", 1, cur, nullptr, 0, 0); if (rc != VH_OK) return rc; }
-        emb.cols.clear(); emb.total = 0;
-        for (int g = 0; g < 2; ++g) for (const Block& b : (g ? sp.dec : sp.enc)) if (b.live && !b.conv) emb.total += b.cout;
         const int kpad = round_up(sp.cemb, 32);
-        emb.wt = cur; cur += (size_t)kpad / 4 * emb.total * 4;
+        emb.wt = base + emb.off;
         e = hipMemsetAsync(emb.wt, 0, (size_t)kpad / 4 * emb.total * 16, n->ctx->stream);
         if (e != hipSuccess) return vh_fail(VH_EHIP, "vh_net_prepare: %s", hipGetErrorString(e));
-        int c0 = 0;
-        for (int g = 0; g < 2; ++g)
-            for (const Block& b : (g ? sp.dec : sp.enc)) {
-                if (!b.live) continue;
-                const std::string p = prefix + (g ? "dec." : "enc.") + b.name + ".";
-                if (b.conv) { rc = prep_one(n, p + "weight", 9, cur, nullptr, 0, 0); if (rc != VH_OK) return rc; continue; }
-                if ((rc = prep_one(n, p + "conv_res0.weight", 9, cur, nullptr, 0, 0)) != VH_OK) return rc;
-                if ((rc = prep_one(n, p + "conv_res1.weight", 9, cur, nullptr, 0, 0)) != VH_OK) return rc;
-                if (b.cin != b.cout && (rc = prep_one(n, p + "conv_skip.weight", 1, cur, nullptr, 0, 0)) != VH_OK) return rc;
-                if (b.heads) {
-                    const int D = b.cout / b.heads;
-                    if ((rc = prep_one(n, p + "attn_qkv.weight", 1, cur, nullptr, 3, D)) != VH_OK) return rc;
-                    if ((rc = prep_one(n, p + "attn_proj.weight", 1, cur, nullptr, 0, 0)) != VH_OK) return rc;
-                    if (b.xattn && (rc = prep_one(n, p + "x_attn_kv.weight", 1, cur, nullptr, 2, D)) != VH_OK) return rc;
-                }
-                vh_prep_weight_args a{};
-                a.w = P(n, p + "emb_linear.weight"); a.cout = b.cout; a.cin = sp.cemb; a.taps = 1; a.cin_pad = round_up(sp.cemb, 4); a.k_pad = kpad;
-                a.gain_ptr = P(n, p + "emb_gain"); a.gain_value = 1.f; a.wt = emb.wt; a.dst_col0 = c0; a.dst_cols = emb.total; a.split = 0;
-                if ((rc = vh_prep_weight(n->ctx, &a)) != VH_OK) return rc;
-                emb.cols[p] = c0; c0 += b.cout;
-            }
-        if (sp.out_channels && (rc = prep_one(n, prefix + "out_conv.weight", 9, cur, P(n, prefix + "out_gain"), 0, 0)) != VH_OK) return rc;
+        for (auto& kv : emb.cols) {
+            vh_prep_weight_args a{};
+            a.w = P(n, kv.first + "emb_linear.weight"); a.cout = n->params[n->pindex.at(kv.first + "emb_linear.weight")].shape[0]; a.cin = sp.cemb; a.taps = 1;
+            a.cin_pad = round_up(sp.cemb, 4); a.k_pad = kpad; a.gain_ptr = P(n, kv.first + "emb_gain"); a.gain_value = 1.f;
+            a.wt = emb.wt; a.dst_col0 = kv.second; a.dst_cols = emb.total; a.split = 0;
+            const int rc = vh_prep_weight(n->ctx, &a);
+            if (rc != VH_OK) return rc;
+        }
     }
     n->prepared = true;
     return VH_OK;
 }
 
 static int net_build(vh_net* n, int B, float* workspace, size_t bytes, Program** out) {
-    VH_REQUIRE(n->prepared, "vh_net: call vh_net_prepare after binding the parameters");
     VH_REQUIRE(B > 0, "vh_net: batch must be positive");
+    VH_REQUIRE(n->prepared || !workspace, "vh_net_record: call vh_net_prepare after binding the parameters");
     auto pr = std::make_unique<Program>();
     pr->B = B;
     Arena dry;
