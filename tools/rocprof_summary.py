@@ -38,23 +38,46 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--out", required=True)
     ap.add_argument("--note", default="")
+    ap.add_argument("--stats-csv", default=None, help="also write the per-kernel statistics as CSV (when the input is a rocpd database)")
     a = ap.parse_args()
     rows = []
-    for r in csv.DictReader(open(find(a.trace, "*kernel_stats.csv"))):
-        rows.append(dict(kernel=short(r["Name"]), calls=int(r["Calls"]), total_ms=float(r["TotalDurationNs"]) / 1e6,
-                         avg_ms=float(r["AverageNs"]) / 1e6, pct=float(r["Percentage"]),
-                         min_ms=float(r["MinNs"]) / 1e6, max_ms=float(r["MaxNs"]) / 1e6))
+    stats_csv = find(a.trace, "*kernel_stats.csv")
+    if stats_csv:
+        for r in csv.DictReader(open(stats_csv)):
+            rows.append(dict(kernel=short(r["Name"]), calls=int(r["Calls"]), total_ms=float(r["TotalDurationNs"]) / 1e6,
+                             avg_ms=float(r["AverageNs"]) / 1e6, pct=float(r["Percentage"]),
+                             min_ms=float(r["MinNs"]) / 1e6, max_ms=float(r["MaxNs"]) / 1e6))
+    else:
+        # rocprofv3's default output on this image is a rocpd SQLite database (views `kernels`, `counters_collection`)
+        import sqlite3
+        db = sqlite3.connect(find(a.trace, "*_results.db"))
+        per = collections.OrderedDict()
+        for name, dur in db.execute("select name, duration from kernels"):
+            e = per.setdefault(name, [0, 0.0, 1e30, 0.0])
+            e[0] += 1; e[1] += dur; e[2] = min(e[2], dur); e[3] = max(e[3], dur)
+        tot = sum(e[1] for e in per.values())
+        for name, (n, t, mn, mx) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            rows.append(dict(kernel=short(name), calls=n, total_ms=t / 1e6, avg_ms=t / n / 1e6, pct=100.0 * t / tot, min_ms=mn / 1e6, max_ms=mx / 1e6))
+        if a.stats_csv:
+            with open(a.stats_csv, "w") as f:
+                f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+                for name, (n, t, mn, mx) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f'"{name}",{n},{t:.0f},{t / n:.1f},{100.0 * t / tot:.4f},{mn:.0f},{mx:.0f}\n')
     pmc = {}
     for cname, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
         if not d:
             continue
         agg = collections.defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(open(find(d, "*counter_collection.csv"))):
-            if r["Counter_Name"] != cname:
-                continue
-            k = short(r["Kernel_Name"])
+        ccsv = find(d, "*counter_collection.csv")
+        if ccsv:
+            recs = ((r["Kernel_Name"], float(r["Counter_Value"])) for r in csv.DictReader(open(ccsv)) if r["Counter_Name"] == cname)
+        else:
+            import sqlite3
+            recs = sqlite3.connect(find(d, "*_results.db")).execute("select kernel_name, value from counters_collection where counter_name = ?", (cname,))
+        for kname, val in recs:
+            k = short(kname)
             agg[k][0] += 1
-            agg[k][1] += float(r["Counter_Value"])
+            agg[k][1] += float(val)
         for k, (n, v) in agg.items():
             pmc.setdefault(k, {})[cname] = dict(calls=n, kib_per_call=v / n)
     for r in rows:

@@ -608,10 +608,13 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     k.ksplit = ksplit;
     k.scratch = a.scratch;
     k.dbg = vh_debug_ptr();
-    // chunk-major K order when the input does not stay in the 256 MB Infinity Cache either: with tap-major order each tap's
-    // re-read then comes from HBM.  Measured: +7..10 % at 256x256 (0.5-1 GB inputs), +3..4 % at 128x128 (0.27-0.54 GB),
-    // +1.6 % at 0.2 GB, -2 % at 67 MB (the per-K-tile pointer selection costs VALU and buys nothing there).
-    // vh_conv_args.korder overrides the size rule; the process-wide knob "conv_korder" (0 tap / 1 chunk) overrides both (A/B runs).
+    // chunk-major K order when a tap's sweep over the input does not stay in the XCD's 4 MB L2: with tap-major order every tap then
+    // re-fetches its input from beyond L2 (the 256 MB Infinity Cache for inputs below ~200 MB, HBM above).  Round 2 switched at 150 MB
+    // (measured +7..10 % at 0.5-1 GB inputs, +1.6 % at 0.2 GB, -2 % at 67 MB in isolation); round 3 switches at 60 MB: inside the network
+    // the step time is unchanged to 0.1 % (319.0 vs 318.6 ms, profiles/r03_ab_conv_korder_threshold.txt) and the convolution family's
+    // fabric traffic drops from 1.54x to 1.26x its algorithmic bytes (1067 -> 873 MB per launch, rocprofv3 FETCH_SIZE / WRITE_SIZE).
+    // vh_conv_args.korder overrides the size rule; the process-wide knobs "conv_korder_mb" (threshold) and "conv_korder" (0 tap / 1 chunk,
+    // overrides everything) exist for A/B runs.
     const int korder_env = vh_knob(VH_KNOB_CONV_KORDER);
     const bool big_input = (double)M * a.cin_pad * 4.0 > 1e6 * (double)vh_knob(VH_KNOB_CONV_KORDER_MB);
     const int korder_arg = a.korder == VH_KORDER_TAP ? 0 : a.korder == VH_KORDER_CHUNK ? 1 : (big_input ? 1 : 0);
