@@ -15,7 +15,11 @@ ap.add_argument("--sr", action="store_true")
 ap.add_argument("--warp", action="store_true")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--top", type=int, default=45, help="lines to print (0 = all)")
+ap.add_argument("--knobs", default="", help="name=value,... passed to vh_set_knob (A/B runs)")
 a = ap.parse_args()
+for kv in filter(None, a.knobs.split(",")):
+    from vivid_amd import _lib
+    _lib.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
 if a.sr:
     cfg = vivid_amd.vivid_sr(a.res)
 elif a.warp:
