@@ -103,6 +103,8 @@ typedef struct {
     int dst_col0, dst_cols;
     int split;           /* 1: bf16 hi/lo split, wt[(k/8)*2 + hl][dst_cols][8 bf16], hl = 0 hi / 1 lo (same byte count);
                             2: the same split, output-channel major: wt[col][(k/8)*2 + hl][8 bf16] (VH_CONV_GLDS256) */
+    int k_off, k_stride; /* split = 2 only, both 0 by default: this weight's K range starts at k_off of rows that are k_stride long - the fused
+                            (3x3 + 1x1) weight of vh_conv_args.src1 is two calls, the 3x3 part at 0 and the 1x1 part at 9*cin_pad */
 } vh_prep_weight_args;
 int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* a);
 
@@ -141,14 +143,19 @@ typedef struct {
     float qscale;
 } vh_qkv_epilogue;
 typedef struct {
-    const float* src0; const float* src1;  /* src1 may be NULL */
+    const float* src0; const float* src1;  /* src1 may be NULL.  fp32: a channel concat with src0 (mp_cat).  bf16x3 + VH_CONV_GLDS256 + taps == 9 (no `up`): an S8
+                                              tensor of c1 channels at the output resolution that enters as a 1-TAP TAIL SEGMENT of the K loop,
+                                                  out = epi( sum over (tap, ci) of src0[pixel+tap][ci] wt[tap*cin_pad+ci][o]  +  sum over ci of src1[pixel][ci] wt[9*cin_pad+ci][o] ),
+                                              i.e. a 3x3 and a 1x1 convolution of two inputs summed in one GEMM: conv_res1 + conv_skip of a decoder
+                                              block, `x = mp_sum(conv_skip(x_cat), conv_res1(y), t)` training/models.py:184-186 with the mp_sum
+                                              coefficients folded into the two weights and VH_EPI_STORE + clip as the epilogue. */
     int c0, c1;                            /* channels of each source (multiples of 4) */
     float scale0, scale1;
     int rows, h, w;                        /* OUTPUT geometry: rows images of h x w pixels */
     int up;
     int taps;                              /* 1 or 9 */
     int pro;
-    const float* wt; int cin_pad, k_pad;   /* from vh_prep_weight: cin_pad % 32 == 0, k_pad == taps*cin_pad */
+    const float* wt; int cin_pad, k_pad;   /* from vh_prep_weight: cin_pad % 32 == 0, k_pad == taps*cin_pad (+ c1 with a bf16x3 tail segment) */
     const float* zeros; size_t zeros_bytes; /* a device buffer of zeros, >= cin_pad*4 + 64 bytes: out-of-image taps and pad
                                               channels are read from it instead of being masked */
     int cout;
@@ -161,7 +168,7 @@ typedef struct {
     int epi;
     const float* cvec; int cvec_ld;        /* SCALE_SILU: cvec[row*cvec_ld + o] */
     const float* res; int res_up;          /* MPSUM */
-    float ta, tb, clip;                    /* clip <= 0: no clipping */
+    float ta, tb, clip;                    /* clip <= 0: no clipping; VH_EPI_STORE clips too when clip > 0 */
     const vh_qkv_epilogue* qkv;            /* VH_EPI_QKV only */
     int stagger;                           /* VH_CONV_GLDS256 scheduling hint: 0 = library default, 1 = stagger the DMA issue of SIMD partner
                                               waves, 2 = do not.  Results are identical (bit for bit). */

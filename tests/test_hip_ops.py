@@ -207,6 +207,61 @@ def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
         assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5
 
 
+@pytest.mark.parametrize("korder", [1, 2])
+@pytest.mark.parametrize("tile,cout,c1,scratch", [(0, 96, 160, True), (0, 384, 768, True), (1, 128, 256, False), (2, 256, 96, False), (3, 128, 64, False),
+                                                  (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False)])
+def test_conv_glds_tail_segment(ctx, tile, cout, c1, scratch, korder):
+    """A bf16x3 second source = 1-tap tail segment of the 3x3 K loop: conv_res1 + conv_skip of a decoder block as ONE GEMM,
+        x = mp_sum(conv_skip(x_cat), conv_res1(y), t) = clip(ta * W_skip x_cat + tb * W_res1 * y)        training/models.py:184-186, 204-205
+    with ta / tb folded into the two weights (vh_prep_weight gain, k_off / k_stride) and VH_EPI_STORE + clip as the epilogue.  Every tile
+    that carries the tail, both K orders, with and without split-K, ragged M, S8 output."""
+    from vivid_amd import _lib as L
+    rows, h, w, cin = 2, 24, 20, cout                          # conv_res1 is Cout -> Cout
+    g = torch.Generator().manual_seed(tile * 100 + cout + c1 + korder)
+    y_in = torch.randn(rows, cin, h, w, generator=g)
+    x_cat = torch.randn(rows, c1, h, w, generator=g)
+    w_res1 = torch.randn(cout, cin, 3, 3, generator=g)
+    w_skip = torch.randn(cout, c1, 1, 1, generator=g)
+    ta, tb, clip = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58), 1.5
+    ref = (ta * R.mp_conv(x_cat, w_skip) + tb * R.mp_conv(y_in, w_res1)).clip(-clip, clip)
+    M = rows * h * w
+    s8 = []
+    for t, c in ((y_in, cin), (x_cat, c1)):
+        td = _nhwc(t).cuda()
+        o = torch.empty(M * c, device="cuda")
+        ctx.call("vh_split", L.SplitArgs(src0=td.data_ptr(), src1=None, c0=c, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=c, out=o.data_ptr(), out_raw=None))
+        s8.append(o)
+    k_pad = 9 * cin + c1
+    wt = torch.zeros(k_pad // 4 * cout * 4, device="cuda")
+    w1d, wsd = w_res1.cuda(), w_skip.cuda()
+    ctx.call("vh_prep_weight", L.PrepWeightArgs(w=w1d.data_ptr(), cout=cout, cin=cin, taps=9, cin_pad=cin, k_pad=9 * cin, gain_ptr=None, gain_value=tb,
+                                                wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2, k_off=0, k_stride=k_pad))
+    ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wsd.data_ptr(), cout=cout, cin=c1, taps=1, cin_pad=c1, k_pad=c1, gain_ptr=None, gain_value=ta,
+                                                wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2, k_off=9 * cin, k_stride=k_pad))
+    out = torch.full((M, cout), float("nan"), device="cuda")
+    o8 = torch.empty(M * cout, device="cuda")
+    ctx.call("vh_conv", L.ConvArgs(src0=s8[0].data_ptr(), src1=s8[1].data_ptr(), c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                  taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                  scratch=_scratch() if scratch else None, scratch_floats=(1 << 22) if scratch else 0, cout=cout, out=out.data_ptr(),
+                                  out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, kernel=1, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0,
+                                  clip=clip, korder=korder, tile=tile))
+    torch.cuda.synchronize()
+    assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
+    assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5
+
+
+def test_conv_tail_segment_is_validated(ctx):
+    from vivid_amd import _lib as L
+    base = dict(src0=_zeros(), src1=_zeros(), c0=32, c1=32, scale0=1.0, scale1=1.0, rows=1, h=8, w=8, pro=0, wt=_zeros(), cin_pad=32,
+                zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0, cout=32, out=_zeros(), out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=0)
+    with pytest.raises(L.VividHipError, match="tail"):
+        ctx.call("vh_conv", L.ConvArgs(up=0, taps=1, k_pad=64, **base))            # 1x1 convolutions have no tail
+    with pytest.raises(L.VividHipError, match="tail"):
+        ctx.call("vh_conv", L.ConvArgs(up=1, taps=9, k_pad=320, **base))           # not with `up`
+    with pytest.raises(L.VividHipError, match="k_pad"):
+        ctx.call("vh_conv", L.ConvArgs(up=0, taps=9, k_pad=288, **base))           # k_pad must cover the tail
+
+
 def test_conv_forced_tile_is_validated(ctx):
     from vivid_amd import _lib as L
     with pytest.raises(L.VividHipError, match="256x256"):

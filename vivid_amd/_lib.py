@@ -25,7 +25,7 @@ class PrepWeightArgs(C.Structure):
     _fields_ = [("w", C.c_void_p), ("cout", C.c_int), ("cin", C.c_int), ("taps", C.c_int),
                 ("cin_pad", C.c_int), ("k_pad", C.c_int), ("gain_ptr", C.c_void_p),
                 ("gain_value", C.c_float), ("wt", C.c_void_p), ("dst_col0", C.c_int), ("dst_cols", C.c_int),
-                ("split", C.c_int)]
+                ("split", C.c_int), ("k_off", C.c_int), ("k_stride", C.c_int)]
 
 
 class QkvEpilogue(C.Structure):

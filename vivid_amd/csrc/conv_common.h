@@ -32,6 +32,7 @@ struct ConvK {
     float ta, tb, clip;
     int M, HW, NT;
     FastDiv div_hw, div_w;          // n / HW and n / w
+    FastDiv div_c0u;                // n / (c0 / 4): a 16-byte-unit offset into src0 back to (pixel, unit) - the tail segment of conv_x3_glds
     // VH_EPI_QKV: attention operand buffers and the key-sequence placement of vh_qkv_split_x3
     float* q; unsigned short* qk; unsigned short* qv; int q_heads, q_nj, q_rows_per_b, q_koff, q_klp, q_d; float q_scale;
     int stagger;                    // conv_x3_glds: waves 4-7 issue their DMA in the middle of their MFMAs instead of before them
@@ -85,6 +86,8 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvK& a, const f32x16 
             }
             y = a.res[rrow * a.cout + gn] * a.ta + y * a.tb;
             if (a.clip > 0.f) y = fminf(fmaxf(y, -a.clip), a.clip);
+        } else if (a.epi == VH_EPI_STORE && a.clip > 0.f) {
+            y = fminf(fmaxf(y, -a.clip), a.clip);
         }
         if (a.out) a.out[(size_t)gm * a.cout + gn] = y;
         if (a.out_s8) store_s8(a.out_s8, (size_t)gm, a.out_s8_c, gn, y);
@@ -150,6 +153,11 @@ __device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int g
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (full || gn + j < a.cout) y[j] = mp_silu_dev(y[j] * cp[j]);
+    } else if (a.epi == VH_EPI_STORE) {
+        if (a.clip > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
+        }
     } else if (a.epi == VH_EPI_MPSUM) {
         size_t rrow = (size_t)gm;
         if (a.res_up) {
@@ -323,6 +331,9 @@ __device__ __forceinline__ void conv_epilogue_block_fast(const ConvK& a, const f
                 y[j] = rv[j] * a.ta + y[j] * a.tb;
                 if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
             }
+        } else if (a.clip > 0.f) {                                   // VH_EPI_STORE with a clip: the fused conv_res1 + conv_skip of a decoder block
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
         }
         const size_t eo = e0 + (size_t)(8 * i) * a.cout;
         if (a.out) *reinterpret_cast<float4*>(a.out + eo) = make_float4(y[0], y[1], y[2], y[3]);

@@ -65,8 +65,12 @@ __device__ __forceinline__ void wait_dma() {
 // 256x64 tile, whose 80 KB of LDS fit twice per CU - two independent workgroups, so that one's prologue / epilogue / turnaround runs
 // under the other's K loop (the full-resolution 64-channel layers of the SR net have K loops of 18 K-tiles: most of a 512x64 tile's time
 // was outside its loop).
-template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16, bool CHUNK, int OCC = 2>
+// TAIL = true: the K loop continues, after the nine taps, over a 1-tap segment read from a second S8 source (vh_conv_args.src1: conv_res1 +
+// conv_skip of a decoder block as one GEMM).  A template parameter so that the plain instantiations keep their register allocation (the
+// 512x128 tile sits 2-20 registers under the limit); the tail's pointers are derived from state that is live in the loop anyway.
+template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16, bool CHUNK, int OCC = 2, bool TAIL = false>
 __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
+    static_assert(!TAIL || TAPS == 9, "the tail segment exists for 3x3 convolutions only");
     static_assert(!CHUNK || TAPS == 9, "chunk-major order exists for 3x3 convolutions only");
     static_assert(WAVES_M * WAVES_N == 8, "8 waves");
     constexpr int BM = WAVES_M * MI * 32, BN = WAVES_N * NI * 32;
@@ -144,7 +148,26 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) pa[j] = ((pmask[j] >> tap) & 1u) ? pc[j] + off : zp;
     };
+    // "tap 9" = the 1-tap tail segment of a fused (3x3 + 1x1) convolution: K-tiles 9*cin_pad/32 ... read the SECOND source (c1 channels,
+    // same pixels, no halo) against the weight columns appended behind the nine taps.  Without `up` the pixel index of row g is g itself.
+    // (its slot coordinates are recomputed from the lane id (mbcnt) and the wave id (kept in an SGPR) instead of being kept in VGPRs across
+    //  the main loop, where the 512x128 tile has none to spare)
+    const int w_s = __builtin_amdgcn_readfirstlane(w);
+    auto setup_tail = [&]() {
+        if constexpr (TAIL) {
+            const int l2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            const int rsub2 = w_s * 8 + (l2 >> 3);
+            const int uslot2 = (l2 & 7) ^ (((w_s & 1) << 2) | (l2 >> 4));
+            const int u2 = M16 ? ((uslot2 & 3) * 2 + (uslot2 >> 2)) : uslot2;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const int gm = m0 + j * 64 + rsub2;
+                pa[j] = gm < a.M ? reinterpret_cast<const float4*>(a.src1 + (size_t)gm * a.c1) + u2 : zp;
+            }
+        }
+    };
     auto setup_tap = [&](int tap) {
+        if (TAIL && tap == 9) { setup_tail(); return; }
         int dy = 0, dx = 0;
         if (TAPS == 9) {
             const int ty = tap / 3;
@@ -277,7 +300,9 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
     // 9 consecutive K-tiles.
     constexpr bool chunk_major = CHUNK;
     int tap, cc;
-    if constexpr (chunk_major) { cc = (kt0 / 9) * BK; tap = kt0 - (kt0 / 9) * 9; setup_tap_fast(tap); }
+    const int kt_tail = TAPS * (a.cin_pad / BK);            // first K-tile of the tail segment (== KTall when there is none)
+    if (TAIL && kt0 >= kt_tail) { tap = 9; cc = (kt0 - kt_tail) * BK; setup_tail(); }
+    else if constexpr (chunk_major) { cc = (kt0 / 9) * BK; tap = kt0 - (kt0 / 9) * 9; setup_tap_fast(tap); }
     else { tap = (kt0 * BK) / a.cin_pad; cc = kt0 * BK - tap * a.cin_pad; setup_tap(tap); }
 #ifdef VH_CLOCK
     const unsigned long long ck_p1 = __builtin_amdgcn_s_memtime();
@@ -302,10 +327,14 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
     unsigned long long ck_m0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #endif
-    for (int kt = 0; kt < KT; ++kt) {
+    // TAIL: the slice's K-tiles are [main tiles of the nine taps | tail tiles]; the main loop below is the plain kernel's, bounded by KTm, and
+    // the tail tiles run in a second, simpler loop (same pixels, next 32 channels of the second source per tile).  Keeping the tail out of the
+    // main loop keeps its register allocation: with the tail's pointer derivation inside it the 512x128 tile spilled in the loop.
+    const int KTm = TAIL ? (kt0 >= kt_tail ? 0 : (kt0 + KT <= kt_tail ? KT : kt_tail - kt0)) : KT;
+    for (int kt = 0; kt < KTm; ++kt) {
         const int st = kt & 1;
         auto fetch_next = [&]() {
-            if (kt + 1 < KT) {
+            if (kt + 1 < KTm) {
                 if constexpr (chunk_major) {
                     if (++tap == 9) { tap = 0; cc += BK; }
                     setup_tap_fast(tap);
@@ -328,6 +357,24 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
 #if !(defined(VH_CONV_ABLATE) && (VH_CONV_ABLATE & 2))
         __syncthreads();                                   // ... and so has every other wave's
 #endif
+    }
+    if constexpr (TAIL) {
+        if (KT > KTm) {
+            if (KTm > 0) {                                     // (KTm == 0: this slice starts inside the tail and its first tile is already staged)
+                tap = 9; cc = 0;
+                setup_tail();
+                issue(KTm & 1, 9, 0);
+                wait_dma();
+                __syncthreads();
+            }
+            for (int kt = KTm; kt < KT; ++kt) {
+                const int st = kt & 1;
+                if (kt + 1 < KT) { cc += BK; issue(st ^ 1, 9, cc); }
+                compute(st, []() {});
+                wait_dma();
+                __syncthreads();
+            }
+        }
     }
 #ifdef VH_CLOCK
     {
@@ -460,6 +507,7 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
     ConvK e = a;
     if (a.ksplit > 1) {                                    // raw partial sums; vh_conv's reducer applies the epilogue
         e.epi = VH_EPI_STORE;
+        e.clip = 0.f;
         e.out = a.scratch + (size_t)ks * a.M * a.cout;
         e.out_s8 = nullptr;
     }
@@ -541,6 +589,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long lo
 }  // namespace
 
 #define VH_LAUNCH(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_>), dim3(grid), dim3(512), 0, s, k)
+#define VH_LAUNCH_TAIL(WM, WN, MI_, NI_, CH_, OCC_) hipLaunchKernelGGL((conv_x3_glds<9, WM, WN, MI_, NI_, true, CH_, OCC_, true>), dim3(grid), dim3(512), 0, s, k)
 #define VH_LAUNCH_OCC4(T, WM, WN, MI_, NI_, CH_) hipLaunchKernelGGL((conv_x3_glds<T, WM, WN, MI_, NI_, true, CH_, 4>), dim3(grid), dim3(512), 0, s, k)
 #define VH_LAUNCH_CFG(T, CH_)                                  \
     do {                                                       \
@@ -583,7 +632,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // Knob "conv_slim2": -1 (default) always, 0 never (the 512x64 tile stays reachable for A/B and through vh_conv_args.tile).
     const int slim2_knob = vh_knob(VH_KNOB_CONV_SLIM2);
     const bool slim2 = slim && (a.tile == VH_TILE_256x64 || (a.tile == VH_TILE_AUTO && slim2_knob != 0));
-    const int BN = wide ? 256 : slim ? 64 : 128, BMt = slim2 ? 256 : (tall || slim) ? 512 : 256;
+    const int BN = wide ? 256 : slim ? 64 : 128, BMt = (slim2 || (slim && a.src1)) ? 256 : (tall || slim) ? 512 : 256;
     const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
     k.NT = (int)NT;
@@ -621,12 +670,22 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     k.korder = (a.taps == 9 && !a.up && a.cin_pad > BK) ? (korder_env >= 0 ? korder_env : korder_arg) : 0;
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
-    const int cfg = slim2 ? 5 : slim ? 3 : tall ? 2 : wide ? 1 : 0;
+    const bool has_tail = a.src1 != nullptr;               // (validated by vh_conv: bf16x3, 3x3, no `up`)
+    const int cfg = (slim2 || (slim && has_tail)) ? 5 : slim ? 3 : tall ? 2 : wide ? 1 : 0;       // (a tail launch with Cout <= 64 always takes the 256x64 tile)
+    if (has_tail && (cfg == 1 || cfg == 2) && a.cin_pad > BK) k.korder = 1;
     const int stagger_env = vh_knob(VH_KNOB_CONV_STAGGER);
     k.stagger = stagger_env >= 0 ? stagger_env : (a.stagger == 1 ? 1 : 0);       // default: off (see the kernel's note on `late`)
     const bool chunk = k.korder != 0;
     return vh_dispatch(ctx, taps == 9 ? VH_TAG_CONV3 : VH_TAG_CONV1, flops, bytes, [k, taps, cfg, chunk, grid](hipStream_t s) -> int {
-        if (taps == 9) { if (chunk) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
+        if (taps == 9 && k.c1 > 0) {
+            // tail instantiations: 256x128 and 256x64 in both K orders; 512x128 and 256x256 chunk-major only (the dispatcher forces that
+            // order for them: tap-major they are 2 registers over the limit, and no launch the size rule makes would take them tap-major)
+            if (cfg == 2) VH_LAUNCH_TAIL(4, 2, 4, 2, true, 2);
+            else if (cfg == 1) VH_LAUNCH_TAIL(2, 4, 4, 2, true, 2);
+            else if (cfg == 5) { if (chunk) VH_LAUNCH_TAIL(8, 1, 1, 2, true, 4); else VH_LAUNCH_TAIL(8, 1, 1, 2, false, 4); }
+            else { if (chunk) VH_LAUNCH_TAIL(4, 2, 2, 2, true, 2); else VH_LAUNCH_TAIL(4, 2, 2, 2, false, 2); }
+        }
+        else if (taps == 9) { if (chunk) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
         else vh_conv_x3_launch_1tap(k, cfg, grid, s);
         if (k.ksplit > 1) {
             const long long total4 = (long long)k.M * ((k.cout + 3) / 4);

@@ -54,9 +54,12 @@ __global__ __launch_bounds__(256) void prep_weight_k(vh_prep_weight_args a) {
         if (a.split == 2) {
             unsigned hi, lo;
             split_bf16(v, hi, lo);
-            unsigned short* ws = reinterpret_cast<unsigned short*>(a.wt) + (size_t)(a.dst_col0 + o) * a.k_pad * 2;
-            ws[(size_t)(k >> 3) * 16 + (k & 7)] = (unsigned short)hi;
-            ws[(size_t)(k >> 3) * 16 + 8 + (k & 7)] = (unsigned short)lo;
+            // row of output channel o: k_stride K elements (0 = k_pad); this weight's K range starts at k_off (a fused 3x3 + 1x1 weight is
+            // written by two calls: the 3x3 part at 0, the 1x1 part behind it)
+            const int kd = a.k_off + k;
+            unsigned short* ws = reinterpret_cast<unsigned short*>(a.wt) + (size_t)(a.dst_col0 + o) * (a.k_stride ? a.k_stride : a.k_pad) * 2;
+            ws[(size_t)(kd >> 3) * 16 + (kd & 7)] = (unsigned short)hi;
+            ws[(size_t)(kd >> 3) * 16 + 8 + (kd & 7)] = (unsigned short)lo;
         } else if (a.split) {
             unsigned hi, lo;
             split_bf16(v, hi, lo);
@@ -570,6 +573,8 @@ extern "C" int vh_prep_weight(vh_ctx* ctx, const vh_prep_weight_args* p) {
     VH_REQUIRE(a.cin_pad >= a.cin && a.cin_pad % 4 == 0, "vh_prep_weight: cin_pad %d", a.cin_pad);
     VH_REQUIRE(a.k_pad % 32 == 0 && a.k_pad >= a.taps * a.cin_pad, "vh_prep_weight: k_pad %d", a.k_pad);
     VH_REQUIRE(a.dst_col0 >= 0 && a.dst_col0 + a.cout <= a.dst_cols, "vh_prep_weight: destination columns out of range");
+    VH_REQUIRE((a.k_off == 0 && a.k_stride == 0) || (a.split == 2 && a.k_off >= 0 && a.k_off % 32 == 0 && a.k_stride % 32 == 0 && a.k_off + a.k_pad <= a.k_stride),
+               "vh_prep_weight: k_off / k_stride place a K range inside a longer row of a split = 2 weight (multiples of 32, k_off + k_pad <= k_stride)");
     return vh_dispatch(ctx, VH_TAG_PREP, 0.0, 4.0 * ((double)a.cout * a.cin * a.taps + (double)a.k_pad * a.cout), [a](hipStream_t s) -> int {
         hipLaunchKernelGGL(prep_weight_k, dim3(a.cout), dim3(256), 0, s, a);
         return vh_check_launch("prep_weight_k");

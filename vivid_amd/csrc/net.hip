@@ -150,7 +150,7 @@ struct Arena {
 };
 struct Buf { long long off = -1; long long n = 0; int c = 0; bool ok() const { return off >= 0; } };   // n floats; c = channels (last dim)
 
-struct Weight { float* wt = nullptr; size_t off = 0; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0, nj = 0, D = 0; const float* gain = nullptr; bool has_gain = false; };
+struct Weight { float* wt = nullptr; size_t off = 0; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0, nj = 0, D = 0, fused_c1 = 0; const float* gain = nullptr; bool has_gain = false; };
 
 struct Program {
     int B = 0;
@@ -203,6 +203,7 @@ template <class F, class A> void call(vh_net* n, F fn, const A& a) { if (n->emit
 struct ConvOpt {
     int up = 0, epi = VH_EPI_STORE; const float* cvec = nullptr; int cvec_ld = 0; const Buf* res = nullptr; int res_up = 0;
     float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr; bool s8_only = false, also_s8 = false; const vh_qkv_epilogue* qkv = nullptr;
+    const Buf* src1 = nullptr;        // S8 second source: the 1-tap tail segment of a fused conv_res1 + conv_skip
 };
 // bf16x3 glds convolution of an S8 source; returns (fp32 out, S8 out) - either may be empty
 std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, int h, int w, ConvOpt o) {
@@ -211,7 +212,7 @@ std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, i
     if ((o.s8_only || o.also_s8) && !o.qkv) out8 = alloc(n, rows, h, w, W.cout);
     if (!o.s8_only && !o.qkv) { if (o.out) out = *o.out; else out = alloc(n, rows, h, w, W.cout); }
     vh_conv_args a{};
-    a.src0 = ptr(n, src); a.src1 = nullptr; a.c0 = src.c; a.c1 = 0; a.scale0 = 1.f; a.scale1 = 1.f;
+    a.src0 = ptr(n, src); a.src1 = o.src1 ? ptr(n, *o.src1) : nullptr; a.c0 = src.c; a.c1 = o.src1 ? o.src1->c : 0; a.scale0 = 1.f; a.scale1 = 1.f;
     a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = VH_PRO_NONE;
     a.wt = W.wt; a.cin_pad = W.cin_pad; a.k_pad = W.k_pad; a.zeros = n->zeros; a.zeros_bytes = ZEROS_FLOATS * 4; a.cout = W.cout;
     a.scratch = n->scratch; a.scratch_floats = SCRATCH_FLOATS;
@@ -290,17 +291,17 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         ConvOpt o0; o0.up = up; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
         Buf y = conv(n, cs.first, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
         release(n, cs.first);
-        Buf xsk;
-        const Buf* res; int res_up;
+        std::pair<Buf, Buf> r;
         if (has_skip_conv) {
-            ConvOpt os; os.up = up;
-            xsk = conv(n, cs.second, n->W.at(p + "conv_skip.weight"), rows, R, R, os).first;
+            // conv_res1 + conv_skip as one GEMM: the raw concat is the 1-tap tail segment, ta / tb are folded into the weights
+            ConvOpt o1; o1.epi = VH_EPI_STORE; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8; o1.src1 = &cs.second;
+            r = conv(n, y, n->W.at(p + "conv_res1+skip"), rows, R, R, o1);
             release(n, cs.second);
-            res = &xsk; res_up = 0;
-        } else { res = &x; res_up = up; }
-        ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = res; o1.res_up = res_up; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
-        auto r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
-        release(n, y); release(n, xsk);
+        } else {
+            ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = &x; o1.res_up = up; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+            r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
+        }
+        release(n, y);
         out = r.first; r_s8 = r.second;
     }
     if (fin_s8) out_s8 = r_s8;
@@ -530,8 +531,16 @@ void layout(vh_net* n) {
                 const std::string p = prefix + (g ? "dec." : "enc.") + b.name + ".";
                 if (b.conv) { add(p + "weight", 9, 0, 0, false); continue; }
                 add(p + "conv_res0.weight", 9, 0, 0, false);
-                add(p + "conv_res1.weight", 9, 0, 0, false);
-                if (b.cin != b.cout) add(p + "conv_skip.weight", 1, 0, 0, false);
+                if (b.dec && b.cin != b.cout) {
+                    // conv_res1 + conv_skip of a decoder block as one GEMM (vh_conv_args.src1): rows of 9*Cout + Cin_pad K elements
+                    Weight w; w.cout = b.cout; w.taps = 9; w.cin_pad = b.cout; w.k_pad = 9 * b.cout + round_up(b.cin, 32); w.off = cur; w.fused_c1 = round_up(b.cin, 32);
+                    cur += (size_t)w.k_pad / 4 * w.cout * 4;
+                    n->W[p + "conv_res1+skip"] = w;
+                    n->prep_order.push_back(p + "conv_res1+skip");
+                } else {
+                    add(p + "conv_res1.weight", 9, 0, 0, false);
+                    if (b.cin != b.cout) add(p + "conv_skip.weight", 1, 0, 0, false);
+                }
                 if (b.heads) {
                     const int D = b.cout / b.heads;
                     const bool fused = (b.res * b.res) % 32 == 0;      // VH_EPI_QKV needs 32 | pixels per image; else vh_qkv_split_x3 on an fp32 tensor
@@ -547,6 +556,20 @@ void layout(vh_net* n) {
 
 int prep_one(vh_net* n, const std::string& key, float* base) {
     Weight& w = n->W.at(key);
+    if (w.fused_c1) {
+        w.wt = base + w.off;
+        const std::string p = key.substr(0, key.size() - std::string("conv_res1+skip").size());
+        const Param& p1 = n->params[n->pindex.at(p + "conv_res1.weight")];
+        const Param& ps = n->params[n->pindex.at(p + "conv_skip.weight")];
+        float ta, tb; mp_sum_coeffs(n->cfg.res_balance, ta, tb);
+        vh_prep_weight_args a{};
+        a.w = p1.ptr; a.cout = w.cout; a.cin = w.cout; a.taps = 9; a.cin_pad = w.cout; a.k_pad = 9 * w.cout; a.gain_ptr = nullptr; a.gain_value = tb;
+        a.wt = w.wt; a.dst_col0 = 0; a.dst_cols = w.cout; a.split = 2; a.k_off = 0; a.k_stride = w.k_pad;
+        int rc = vh_prep_weight(n->ctx, &a);
+        if (rc != VH_OK) return rc;
+        a.w = ps.ptr; a.cin = ps.shape[1]; a.taps = 1; a.cin_pad = w.fused_c1; a.k_pad = w.fused_c1; a.gain_value = ta; a.k_off = 9 * w.cout;
+        return vh_prep_weight(n->ctx, &a);
+    }
     const Param& p = n->params[n->pindex.at(key)];
     w.wt = base + w.off;
     const int cout = p.shape[0], cin = p.shape[1];

@@ -127,6 +127,8 @@ class Engine:
         self.conv_stagger = 0                 # vh_conv scheduling hint: 0 = library default (the 512x128 tile staggers, the others do not)
         # attn_qkv / x_attn_kv write q, k, v^T from their own epilogue (glds kernel)
         self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0"
+        # decoder blocks: conv_res1 and conv_skip as one GEMM (a 1-tap tail segment of the 3x3 K loop)
+        self.fuse_skip = os.environ.get("VIVID_FUSE_SKIP", "1") != "0"
         self.cfg = cfg
         self.std_filter = tuple(float(v) for v in cfg.resample_filter) == (1.0, 1.0)
         self.dual = dual_source
@@ -191,9 +193,12 @@ class Engine:
                     self._prep_conv(p + "weight", 9)
                     continue
                 self._prep_conv(p + "conv_res0.weight", 9)
-                self._prep_conv(p + "conv_res1.weight", 9)
-                if b.cin != b.cout:
-                    self._prep_conv(p + "conv_skip.weight", 1)
+                if self._fused_skip(b):
+                    self._prep_fused_res1_skip(p, b)
+                else:
+                    self._prep_conv(p + "conv_res1.weight", 9)
+                    if b.cin != b.cout:
+                        self._prep_conv(p + "conv_skip.weight", 1)
                 if b.heads:
                     fused = self._qkv_fused(b)
                     self._prep_conv(p + "attn_qkv.weight", 1, qkv_perm=(3, b.cout // b.heads) if fused else None)
@@ -218,6 +223,26 @@ class Engine:
         if not (self.x3 and self.glds and self.fuse_qkv and b.heads):
             return False
         return b.cout % 32 == 0 and b.cin % 32 == 0 and b.cout // b.heads in (32, 64) and (b.res * b.res) % 32 == 0
+
+    def _fused_skip(self, b: BlockSpec) -> bool:
+        """Decoder blocks with a skip convolution, bf16x3 glds path: `x = mp_sum(conv_skip(x_cat), conv_res1(y), t)` (training/models.py:184-186) is
+        ONE GEMM - K = 9*Cout (y, 3x3) + Cin (x_cat, 1 tap), the mp_sum coefficients folded into the two weights - instead of a 1x1 launch, its
+        fp32 output and a residual read (vh_conv_args.src1 as a tail segment)."""
+        return (self.x3 and self.glds and self.fuse_skip and b.kind == "block" and b.flavor == "dec" and b.cin != b.cout
+                and b.cout % 32 == 0 and b.cin % 32 == 0)
+
+    def _prep_fused_res1_skip(self, p: str, b: BlockSpec):
+        ta, tb = self._mp_sum_coeffs(self.cfg.res_balance)
+        w1, ws = self._params[p + "conv_res1.weight"], self._params[p + "conv_skip.weight"]
+        cout, c1 = b.cout, _round_up(b.cin, 32)
+        k_pad = 9 * cout + c1
+        wt = torch.empty(k_pad // 4 * cout * 4, dtype=torch.float32, device=w1.device)
+        if w1.numel():
+            for w, taps, cin, cin_pad, gain, k_off in ((w1, 9, cout, cout, tb, 0), (ws, 1, b.cin, c1, ta, 9 * cout)):
+                self.ctx.call("vh_prep_weight", L.PrepWeightArgs(w=w.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin_pad, k_pad=taps * cin_pad,
+                                                                 gain_ptr=None, gain_value=gain, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2,
+                                                                 k_off=k_off, k_stride=k_pad))
+        self.W[p + "conv_res1+skip"] = Weight(wt, cout, k_pad, cout, 9)
 
     def _prep_conv(self, key: str, taps: int, gain: Optional[torch.Tensor] = None, qkv_perm: Optional[Tuple[int, int]] = None):
         w = self._params[key]
@@ -264,6 +289,8 @@ class Engine:
                     if b.live and b.kind == "block":
                         cols[f"{prefix}{grp}.{b.name}."] = c0
                         c0 += b.cout
+                        if self._fused_skip(b):
+                            self.W[f"{prefix}{grp}.{b.name}.conv_res1+skip"] = Weight(dummy, b.cout, 9 * b.cout + _round_up(b.cin, 32), b.cout, 9)
                 self.embW[prefix] = (dummy, cols, c0)
         try:
             self._A, self._emit, self._backing = Arena(), False, None
@@ -441,18 +468,25 @@ class Engine:
             else:
                 y = self._conv(srcs, self.W[p + "conv_res0.weight"], rows, R, R, up=up, pro=L_PRO_SILU,
                                epi=L_EPI_SCALE_SILU, cvec=cv)
-            if has_skip_conv:
-                if x3:
-                    xsk = self._conv([(craw, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R, up=up, prec=1)
-                    self._free(craw)
-                else:
-                    xsk = self._conv(srcs, self.W[p + "conv_skip.weight"], rows, R, R, up=up)
-                res, res_up = xsk, 0
+            if has_skip_conv and x3 and self._fused_skip(b):
+                # conv_res1 + conv_skip as one GEMM: the raw concat enters as the 1-tap tail of the K loop, ta / tb are in the weights
+                r = self._conv([(y, 1.0), (craw, 1.0)], self.W[p + "conv_res1+skip"], rows, R, R, epi=L_EPI_STORE, clip=clip_res, prec=1,
+                               also_s8=res1_s8 or fin_s8)
+                self._free(craw)
+                xsk = None
             else:
-                assert skip is None
-                xsk, res, res_up = None, x, up
-            r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
-                           res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
+                if has_skip_conv:
+                    if x3:
+                        xsk = self._conv([(craw, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R, up=up, prec=1)
+                        self._free(craw)
+                    else:
+                        xsk = self._conv(srcs, self.W[p + "conv_skip.weight"], rows, R, R, up=up)
+                    res, res_up = xsk, 0
+                else:
+                    assert skip is None
+                    xsk, res, res_up = None, x, up
+                r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
+                               res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
             self._free(y)
             self._free(xsk)
             self._free(xup)
@@ -776,6 +810,7 @@ class Engine:
 
 
 L_PRO_SILU = 1
+L_EPI_STORE = 0
 L_EPI_SCALE_SILU = 1
 L_EPI_MPSUM = 2
 L_EPI_QKV = 3
