@@ -168,6 +168,8 @@ typedef struct {
     int epi;
     const float* cvec; int cvec_ld;        /* SCALE_SILU: cvec[row*cvec_ld + o] */
     const float* res; int res_up;          /* MPSUM */
+    const float* res_scale;                /* MPSUM, optional [rows*h*w] (not with res_up): the residual is res[m][o] * res_scale[m] - a pixel-normalised
+                                              tensor given as its raw values and vh_pixnorm's per-pixel factor */
     float ta, tb, clip;                    /* clip <= 0: no clipping; VH_EPI_STORE clips too when clip > 0 */
     const vh_qkv_epilogue* qkv;            /* VH_EPI_QKV only */
     int stagger;                           /* VH_CONV_GLDS256 scheduling hint: 0 = library default, 1 = stagger the DMA issue of SIMD partner
@@ -197,6 +199,9 @@ typedef struct {
     int pool;
     int norm;     /* 0: pooling only */
     void* out_s8; /* optional: mp_silu(out) in the S8 layout (c % 32 == 0), the conv_res0 input of :174 */
+    float* scale_out; /* optional [rows*h*w]: the per-pixel factor 1 / (1e-4 + ||v||/sqrt(C)).  With it (and out_s8) `out` may be NULL: the
+                         normalised tensor is then never materialised - its one other reader, the residual of conv_res1 (:184), takes
+                         x * scale[pixel] instead (vh_conv_args.res_scale) */
 } vh_pixnorm_args;
 int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* a);
 

@@ -378,6 +378,46 @@ def test_pixnorm_and_s8(ctx, pool):
     assert rel_l2(_s8_decode(s8, (rows, h, w, c)).cpu(), _nhwc(R.mp_silu(ref))) < 2e-5
 
 
+@pytest.mark.parametrize("c", [96, 640])                    # register form / one-pixel-per-wave form
+def test_pixnorm_scale_only_and_conv_residual_scale(ctx, c):
+    """A plain encoder block never materialises normalize(x): vh_pixnorm writes mp_silu(normalize(x)) as S8 plus the per-pixel
+    factor, and conv_res1's residual mp_sum(normalize(x), conv, t) (training/models.py:171, 184) is x * scale[pixel] in the epilogue."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(c)
+    rows, h, w = 2, 6, 10
+    x = torch.randn(rows, c, h, w, generator=g) * 2
+    xn = R.normalize(x, dim=1)
+    xd = _nhwc(x).cuda()
+    M = rows * h * w
+    s8 = torch.empty(M * c, device="cuda")
+    sc = torch.full((M,), float("nan"), device="cuda")
+    ctx.call("vh_pixnorm", L.PixnormArgs(inp=xd.data_ptr(), out=None, rows=rows, h=h, w=w, c=c, pool=0, norm=1, out_s8=s8.data_ptr(), scale_out=sc.data_ptr()))
+    torch.cuda.synchronize()
+    want_scale = (1.0 / (1e-4 + x.square().sum(1).sqrt() / math.sqrt(c))).reshape(-1)
+    assert rel_l2(sc.cpu(), want_scale) < 1e-6
+    assert rel_l2(_s8_decode(s8, (rows, h, w, c)).cpu(), _nhwc(R.mp_silu(xn))) < 2e-5
+    with pytest.raises(L.VividHipError, match="out may be NULL only"):
+        ctx.call("vh_pixnorm", L.PixnormArgs(inp=xd.data_ptr(), out=None, rows=rows, h=h, w=w, c=c, pool=0, norm=1, out_s8=s8.data_ptr()))
+    # conv_res1 with the raw x as residual and the per-pixel factor, with and without split-K, against mp_sum(normalize(x), conv(y))
+    cout = c
+    y_in = torch.randn(rows, 64, h, w, generator=g)
+    wgt = torch.randn(cout, 64, 3, 3, generator=g)
+    ta, tb, clip = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58), 2.0
+    ref = (xn * ta + R.mp_conv(y_in, wgt) * tb).clip(-clip, clip)
+    yd = _nhwc(y_in).cuda()
+    ys8 = torch.empty(M * 64, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=yd.data_ptr(), src1=None, c0=64, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=64, out=ys8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+    for scratch in (None, _scratch()):
+        out = torch.full((M, cout), float("nan"), device="cuda")
+        ctx.call("vh_conv", L.ConvArgs(src0=ys8.data_ptr(), src1=None, c0=64, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0,
+                                      wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=scratch,
+                                      scratch_floats=(1 << 22) if scratch else 0, cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0, prec=1, kernel=1,
+                                      epi=2, cvec=None, cvec_ld=0, res=xd.data_ptr(), res_up=0, res_scale=sc.data_ptr(), ta=ta, tb=tb, clip=clip))
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
+
+
 # the last two: one (batch, head) slice of the headline workload's 128x128-level attention - S = 16384 queries against
 # 49152 keys (self + two source views) in the net, against 16384 keys + 32768 closed-form zero keys in the guidance net
 ATT_BIG = [(1, 1, 16384, 49152, 64, 0), (1, 1, 16384, 16384, 64, 32768)]

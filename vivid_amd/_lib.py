@@ -41,14 +41,14 @@ class ConvArgs(C.Structure):
                 ("zeros", C.c_void_p), ("zeros_bytes", C.c_size_t), ("cout", C.c_int),
                 ("scratch", C.c_void_p), ("scratch_floats", C.c_size_t), ("out", C.c_void_p), ("out_s8", C.c_void_p), ("out_s8_c", C.c_int),
                 ("prec", C.c_int), ("kernel", C.c_int), ("epi", C.c_int),
-                ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int),
+                ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int), ("res_scale", C.c_void_p),
                 ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p), ("stagger", C.c_int),
                 ("korder", C.c_int), ("tile", C.c_int)]
 
 
 class PixnormArgs(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("h", C.c_int),
-                ("w", C.c_int), ("c", C.c_int), ("pool", C.c_int), ("norm", C.c_int), ("out_s8", C.c_void_p)]
+                ("w", C.c_int), ("c", C.c_int), ("pool", C.c_int), ("norm", C.c_int), ("out_s8", C.c_void_p), ("scale_out", C.c_void_p)]
 
 
 class SplitArgs(C.Structure):

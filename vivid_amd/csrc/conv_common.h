@@ -29,6 +29,7 @@ struct ConvK {
     float* out; unsigned short* out_s8; int out_s8_c; int epi;
     const float* cvec; int cvec_ld;
     const float* res; int res_up;
+    const float* res_scale;         // optional per-pixel factor of the residual (MPSUM): res[m][o] * res_scale[m]
     float ta, tb, clip;
     int M, HW, NT;
     FastDiv div_hw, div_w;          // n / HW and n / w
@@ -84,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvK& a, const f32x16 
                 const int yy = fastdiv(rem, a.div_w), xx = rem - yy * a.w;
                 rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
             }
-            y = a.res[rrow * a.cout + gn] * a.ta + y * a.tb;
+            y = a.res[rrow * a.cout + gn] * (a.res_scale ? a.ta * a.res_scale[rrow] : a.ta) + y * a.tb;
             if (a.clip > 0.f) y = fminf(fmaxf(y, -a.clip), a.clip);
         } else if (a.epi == VH_EPI_STORE && a.clip > 0.f) {
             y = fminf(fmaxf(y, -a.clip), a.clip);
@@ -142,9 +143,10 @@ __device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int g
         for (int j = 0; j < 4; ++j) y[j] = mp_silu_dev(y[j] * c[j]);
     } else if (aux && a.epi == VH_EPI_MPSUM) {
         const float rv[4] = {aux->x, aux->y, aux->z, aux->w};
+        const float ta = a.res_scale ? a.ta * a.res_scale[gm] : a.ta;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j] = rv[j] * a.ta + y[j] * a.tb;
+            y[j] = rv[j] * ta + y[j] * a.tb;
             if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
         }
     } else if (a.epi == VH_EPI_SCALE_SILU) {
@@ -176,9 +178,10 @@ __device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int g
 #pragma unroll
             for (int j = 0; j < 4; ++j) rv[j] = (gn + j < a.cout) ? rp[j] : 0.f;
         }
+        const float ta = a.res_scale ? a.ta * a.res_scale[rrow] : a.ta;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j] = rv[j] * a.ta + y[j] * a.tb;
+            y[j] = rv[j] * ta + y[j] * a.tb;
             if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
         }
     }
@@ -208,7 +211,7 @@ __device__ __forceinline__ void conv_epilogue_vec4(const ConvK& a, int gm, int g
 // The residual / cvec values the read-out of block (row0, col0) will need, fetched AHEAD of it: the epilogue walks its 32x32
 // blocks one after the other, each ending in stores the compiler may not move the next block's loads across, so without
 // this every block waits out one full global-load latency.  Valid only when `ok` (aligned, whole vectors in range).
-struct EpiAux { float4 v[4]; bool ok; };
+struct EpiAux { float4 v[4]; float rs[4]; bool ok; };      // rs: ta * res_scale of the four rows (ta when there is no res_scale)
 __device__ __forceinline__ EpiAux conv_epilogue_prefetch(const ConvK& a, int row0, int col0, int lane) {
     EpiAux x;
     const int cg = lane & 7, rsub = lane >> 3;
@@ -217,6 +220,7 @@ __device__ __forceinline__ EpiAux conv_epilogue_prefetch(const ConvK& a, int row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         x.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        x.rs[i] = a.ta;
         const int gm = row0 + rsub + 8 * i;
         if (!x.ok || gm >= a.M || gn + 3 >= a.cout) continue;
         if (a.epi == VH_EPI_MPSUM) {
@@ -290,10 +294,13 @@ __device__ __forceinline__ EpiAux conv_epilogue_prefetch_fast(const ConvK& a, in
                 rrow = (size_t)((img * Hr + (yy >> 1)) * Wr + (xx >> 1));
             }
             x.v[i] = *reinterpret_cast<const float4*>(a.res + rrow * a.cout + gn);
+            x.rs[i] = a.res_scale ? a.ta * a.res_scale[rrow] : a.ta;
         } else if (EPI == VH_EPI_SCALE_SILU) {
             x.v[i] = *reinterpret_cast<const float4*>(a.cvec + (size_t)fastdiv(gm, a.div_hw) * a.cvec_ld + gn);
+            x.rs[i] = 0.f;
         } else {
             x.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x.rs[i] = 0.f;
         }
     }
     return x;
@@ -328,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue_block_fast(const ConvK& a, const f
             const float rv[4] = {aux.v[i].x, aux.v[i].y, aux.v[i].z, aux.v[i].w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                y[j] = rv[j] * a.ta + y[j] * a.tb;
+                y[j] = rv[j] * aux.rs[i] + y[j] * a.tb;
                 if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
             }
         } else if (a.clip > 0.f) {                                   // VH_EPI_STORE with a clip: the fused conv_res1 + conv_skip of a decoder block

@@ -273,6 +273,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     }
     VH_REQUIRE(a.epi != VH_EPI_SCALE_SILU || (a.cvec && a.cvec_ld >= a.cout), "vh_conv: SCALE_SILU needs cvec with ld >= cout");
     VH_REQUIRE(a.epi != VH_EPI_MPSUM || a.res, "vh_conv: MPSUM needs res");
+    VH_REQUIRE(!a.res_scale || (a.epi == VH_EPI_MPSUM && !a.res_up), "vh_conv: res_scale belongs to an MPSUM epilogue without res_up");
     VH_REQUIRE(!(a.epi == VH_EPI_MPSUM && a.res_up) || (a.h % 2 == 0 && a.w % 2 == 0), "vh_conv: res_up needs even output size");
     const long long M = (long long)a.rows * a.h * a.w;
     VH_REQUIRE(M < (1LL << 31) - BM, "vh_conv: too many pixels");
@@ -283,7 +284,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.src0 = a.src0; k.src1 = a.src1; k.zeros = a.zeros; k.c0 = a.c0; k.c1 = a.c1; k.scale0 = a.scale0; k.scale1 = a.scale1;
     k.h = a.h; k.w = a.w; k.up = a.up ? 1 : 0; k.pro = a.pro;
     k.wt = reinterpret_cast<const float4*>(a.wt); k.cin_pad = a.cin_pad; k.k_pad = a.k_pad; k.cout = a.cout;
-    k.out = a.out; k.out_s8 = static_cast<unsigned short*>(a.out_s8); k.out_s8_c = a.out_s8_c; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0;
+    k.out = a.out; k.out_s8 = static_cast<unsigned short*>(a.out_s8); k.out_s8_c = a.out_s8_c; k.epi = a.epi; k.cvec = a.cvec; k.cvec_ld = a.cvec_ld; k.res = a.res; k.res_up = a.res_up ? 1 : 0; k.res_scale = a.res_scale;
     k.ta = a.ta; k.tb = a.tb; k.clip = a.clip;
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
     k.div_hw = fastdiv_make((unsigned)(a.h * a.w)); k.div_w = fastdiv_make((unsigned)a.w); k.div_c0u = fastdiv_make((unsigned)(a.c0 / 4));

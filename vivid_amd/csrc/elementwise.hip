@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long np
         src[0] = reinterpret_cast<const float4*>(a.in + (size_t)p * a.c);
         src[1] = src[2] = src[3] = src[0];
     }
-    float4* dst = reinterpret_cast<float4*>(a.out + (size_t)p * a.c);
+    float4* dst = a.out ? reinterpret_cast<float4*>(a.out + (size_t)p * a.c) : nullptr;
     auto fetch = [&](int i) {
         float4 v = src[0][i];
         if (nsrc == 4) {
@@ -118,10 +118,11 @@ __global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long np
         scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
     }
     unsigned short* s8 = a.out_s8 ? static_cast<unsigned short*>(a.out_s8) + (size_t)p * a.c * 2 : nullptr;
+    if (a.scale_out && lane == 0) a.scale_out[p] = scale;
     for (int i = lane; i < c4; i += 64) {
         float4 v = fetch(i);
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        dst[i] = v;
+        if (dst) dst[i] = v;
         if (s8) {       // mp_silu(out), bf16 hi/lo: chunk of 8 channels = [hi x8 | lo x8], this float4 is half of one
             const float e[4] = {mp_silu_dev(v.x), mp_silu_dev(v.y), mp_silu_dev(v.z), mp_silu_dev(v.w)};
             unsigned h[4], l[4];
@@ -191,15 +192,16 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
             scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
         }
         if (p >= npix) continue;
-        float4* dst = reinterpret_cast<float4*>(a.out + (size_t)p * a.c);
+        float4* dst = a.out ? reinterpret_cast<float4*>(a.out + (size_t)p * a.c) : nullptr;
         unsigned short* s8 = a.out_s8 ? static_cast<unsigned short*>(a.out_s8) + (size_t)p * a.c * 2 : nullptr;
+        if (a.scale_out && li == 0) a.scale_out[p] = scale;
 #pragma unroll
         for (int n = 0; n < NV; ++n) {
             const int i = li + LPP * n;
             if (i >= c4) continue;
             float4 t = v[q][n];
             t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
-            dst[i] = t;
+            if (dst) dst[i] = t;
             if (s8) {
                 const float e[4] = {mp_silu_dev(t.x), mp_silu_dev(t.y), mp_silu_dev(t.z), mp_silu_dev(t.w)};
                 unsigned h[4], l[4];
@@ -600,12 +602,12 @@ extern "C" int vh_split(vh_ctx* ctx, const vh_split_args* p) {
 extern "C" int vh_pixnorm(vh_ctx* ctx, const vh_pixnorm_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_pixnorm: null args");
     const vh_pixnorm_args a = *p;
-    VH_REQUIRE(a.in && a.out, "vh_pixnorm: null tensor");
+    VH_REQUIRE(a.in && (a.out || (a.out_s8 && a.scale_out && a.norm)), "vh_pixnorm: null tensor (out may be NULL only when out_s8 and scale_out are given)");
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.c > 0 && a.c % 4 == 0, "vh_pixnorm: bad geometry (c must be a multiple of 4)");
     VH_REQUIRE(vh_aligned16(a.in) && vh_aligned16(a.out) && vh_aligned16(a.out_s8), "vh_pixnorm: pointers must be 16-byte aligned");
     VH_REQUIRE(!a.out_s8 || a.c % 32 == 0, "vh_pixnorm: S8 output needs c %% 32 == 0 (got %d)", a.c);
     const long long npix = (long long)a.rows * a.h * a.w;
-    return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * ((a.pool ? 5.0 : 2.0) + (a.out_s8 ? 1.0 : 0.0)), [a, npix](hipStream_t s) -> int {
+    return vh_dispatch(ctx, VH_TAG_PIXNORM, 0.0, 4.0 * (double)npix * a.c * ((a.pool ? 4.0 : 1.0) + (a.out ? 1.0 : 0.0) + (a.out_s8 ? 1.0 : 0.0)), [a, npix](hipStream_t s) -> int {
         const int c4 = a.c >> 2;
         const bool inplace_pool = a.pool && a.in == a.out;       // (never used by the engine; the register form reads neighbours late)
 #define VH_PIX(NV_, LPP_)                                                                                                         \

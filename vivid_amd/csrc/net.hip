@@ -204,6 +204,7 @@ struct ConvOpt {
     int up = 0, epi = VH_EPI_STORE; const float* cvec = nullptr; int cvec_ld = 0; const Buf* res = nullptr; int res_up = 0;
     float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr; bool s8_only = false, also_s8 = false; const vh_qkv_epilogue* qkv = nullptr;
     const Buf* src1 = nullptr;        // S8 second source: the 1-tap tail segment of a fused conv_res1 + conv_skip
+    const Buf* res_scale = nullptr;   // per-pixel factor of the residual
 };
 // bf16x3 glds convolution of an S8 source; returns (fp32 out, S8 out) - either may be empty
 std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, int h, int w, ConvOpt o) {
@@ -218,7 +219,7 @@ std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, i
     a.scratch = n->scratch; a.scratch_floats = SCRATCH_FLOATS;
     a.out = ptr(n, out); a.out_s8 = ptr(n, out8); a.out_s8_c = out8.ok() ? W.cout : 0;
     a.prec = VH_PREC_BF16X3; a.kernel = VH_CONV_GLDS256; a.epi = o.epi; a.cvec = o.cvec; a.cvec_ld = o.cvec_ld;
-    a.res = o.res ? ptr(n, *o.res) : nullptr; a.res_up = o.res_up; a.ta = o.ta; a.tb = o.tb; a.clip = o.clip; a.qkv = o.qkv;
+    a.res = o.res ? ptr(n, *o.res) : nullptr; a.res_up = o.res_up; a.res_scale = o.res_scale ? ptr(n, *o.res_scale) : nullptr; a.ta = o.ta; a.tb = o.tb; a.clip = o.clip; a.qkv = o.qkv;
     a.stagger = 0; a.korder = VH_KORDER_AUTO; a.tile = VH_TILE_AUTO;
     call(n, vh_conv, a);
     return {out, out8};
@@ -253,7 +254,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
     const long long npix = (long long)rows * R * R;
     Buf out, r_s8, out_s8;
     if (!b.dec) {
-        Buf xs = alloc(n, rows, R, R, C), xn;
+        Buf xs = alloc(n, rows, R, R, C), xn, res_scale;
         vh_pixnorm_args pa{}; pa.rows = rows; pa.h = R; pa.w = R; pa.c = C; pa.norm = 1; pa.out_s8 = nullptr;
         if (b.resample == 2) {
             xn = alloc(n, rows, R, R, C);
@@ -266,16 +267,18 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
             pa.in = ptr(n, xn); pa.out = ptr(n, xn); pa.pool = 0; pa.out_s8 = ptr(n, xs);
             call(n, vh_pixnorm, pa);
         } else {
-            xn = alloc(n, rows, R, R, C);
-            pa.in = ptr(n, x); pa.out = ptr(n, xn); pa.pool = 0; pa.out_s8 = ptr(n, xs);
+            // plain block: the normalised tensor is never materialised - conv_res1's residual is x * scale[pixel]
+            res_scale = alloc(n, rows, R, R, 1);
+            pa.in = ptr(n, x); pa.out = nullptr; pa.pool = 0; pa.out_s8 = ptr(n, xs); pa.scale_out = ptr(n, res_scale);
             call(n, vh_pixnorm, pa);
         }
         ConvOpt o0; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
         Buf y = conv(n, xs, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
         release(n, xs);
-        ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = &xn; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+        ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = xn.ok() ? &xn : &x; o1.res_scale = res_scale.ok() ? &res_scale : nullptr;
+        o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
         auto r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
-        release(n, y); release(n, xn);
+        release(n, y); release(n, xn); release(n, res_scale);
         out = r.first; r_s8 = r.second;
     } else {
         const int up = b.resample == 1 ? 1 : 0;

@@ -129,6 +129,8 @@ class Engine:
         self.fuse_qkv = os.environ.get("VIVID_FUSE_QKV", "1") != "0"
         # decoder blocks: conv_res1 and conv_skip as one GEMM (a 1-tap tail segment of the 3x3 K loop)
         self.fuse_skip = os.environ.get("VIVID_FUSE_SKIP", "1") != "0"
+        # plain encoder blocks: residual of conv_res1 as x * scale[pixel] instead of a stored pixel-normalised copy
+        self.scale_residual = os.environ.get("VIVID_SCALE_RESIDUAL", "1") != "0"
         self.cfg = cfg
         self.std_filter = tuple(float(v) for v in cfg.resample_filter) == (1.0, 1.0)
         self.dual = dual_source
@@ -321,7 +323,7 @@ class Engine:
             self.hook(name, buf.view(self._backing).clone())
 
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
-              cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0,
+              cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0, res_scale: Optional[Buf] = None,
               ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False, qkv=None):
         """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8;
         also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned.
@@ -345,7 +347,8 @@ class Engine:
                        out=out.ptr if out is not None else None, out_s8=out_s8.ptr if out_s8 is not None else None,
                        out_s8_c=W.cout if out_s8 is not None else 0, prec=prec, kernel=1 if (prec and self.glds) else 0, epi=epi,
                        cvec=cvec[0] if cvec else None, cvec_ld=cvec[1] if cvec else 0,
-                       res=res.ptr if res is not None else None, res_up=res_up, ta=ta, tb=tb, clip=clip,
+                       res=res.ptr if res is not None else None, res_up=res_up, res_scale=res_scale.ptr if res_scale is not None else None,
+                       ta=ta, tb=tb, clip=clip,
                        qkv=C.addressof(qkv) if qkv is not None else None,
                        stagger=self.conv_stagger if (prec and self.glds) else 0)
         self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}")
@@ -416,6 +419,7 @@ class Engine:
         if b.flavor == "enc":
             xs = self._alloc(rows, R, R, C) if x3 else None      # S8 of mp_silu(xn): conv_res0's input
             xs_ptr = xs.ptr if xs is not None else None
+            res_scale = res_src = None
             if b.resample == "down" and self.std_filter:
                 xn = self._alloc(rows, R, R, C)
                 self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=1, norm=1, out_s8=xs_ptr))
@@ -430,6 +434,12 @@ class Engine:
                 else:
                     xn = self._conv([(x, 1.0)], self.W[p + "conv_skip.weight"], rows, R, R)
                 self._call("vh_pixnorm", L.PixnormArgs(inp=xn.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=0, norm=1, out_s8=xs_ptr))
+            elif x3 and self.scale_residual:
+                # the normalised tensor is never materialised: its S8 mp_silu form feeds conv_res0, and its other reader - the residual of
+                # conv_res1 - takes x * scale[pixel] (4 of this pass's 12 bytes per element saved)
+                xn, res_src = None, x
+                res_scale = self._alloc(rows, R, R, 1)
+                self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=None, rows=rows, h=R, w=R, c=C, pool=0, norm=1, out_s8=xs_ptr, scale_out=res_scale.ptr))
             else:
                 xn = self._alloc(rows, R, R, C)
                 self._call("vh_pixnorm", L.PixnormArgs(inp=x.ptr, out=xn.ptr, rows=rows, h=R, w=R, c=C, pool=0, norm=1, out_s8=xs_ptr))
@@ -438,10 +448,11 @@ class Engine:
                 self._free(xs)
             else:
                 y = self._conv([(xn, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, pro=L_PRO_SILU, epi=L_EPI_SCALE_SILU, cvec=cv)
-            r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn,
-                           ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
+            r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn if xn is not None else res_src,
+                           res_scale=res_scale, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
             self._free(y)
             self._free(xn)
+            self._free(res_scale)
         else:
             up = 1 if b.resample == "up" else 0
             xup = None
