@@ -492,6 +492,19 @@ int vh_net_record(vh_net* net, int batch, void* workspace, size_t bytes);
  * out [batch][3][R][R]; rows = batch * (dual_source ? 2 : 1); device fp32, contiguous.  Odd rows of x / sigma are ignored in
  * dual-source mode, like the reference (:676-678). */
 int vh_net_run(vh_net* net, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out);
+/* The two halves of an evaluation as separate programs (training/models.py:664-667 and :676-683), for samplers: the encoder sees
+ * (src, sigma, geometry) only - never x - and a sampler knows its noise levels in advance, so it can evaluate the encoder ONCE per
+ * level (the Heun probe of step i and the Euler call of step i+1 share one) and one level ahead on another stream.
+ *   VH_NET_FEATURES  encoder only; the features stay in that program's workspace (two slots, so that one can be filled while the
+ *                    other is read);
+ *   VH_NET_BOUND     UNet only, reading the features of the VH_NET_FEATURES program of the same (slot, batch) in place - record that
+ *                    one first.  `src` is read only by warp_depth_coor nets (may be NULL otherwise).
+ * vh_net_encode + vh_net_run_bound == vh_net_run, bit for bit. */
+enum { VH_NET_FULL = 0, VH_NET_FEATURES = 1, VH_NET_BOUND = 2 };
+size_t vh_net_workspace_bytes_mode(vh_net* net, int mode, int batch);
+int vh_net_record_mode(vh_net* net, int mode, int slot, int batch, void* workspace, size_t bytes);
+int vh_net_encode(vh_net* net, int slot, int batch, const float* src, const float* sigma, const float* geometry);
+int vh_net_run_bound(vh_net* net, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,29 @@ def test_c_net_reference_base_preset(batch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["tiny_dual", "tiny_sr", "tiny_warp"])
+def test_c_net_split_evaluation_equals_whole(name):
+    """vh_net_encode + vh_net_run_bound (the sampler's split evaluation: encoder once per noise level into a feature slot, UNet on that
+    slot in place) == vh_net_run, bit for bit; the two slots are independent."""
+    case = CASES[name]
+    py, cn = _pair(case["cfg"], case["seed"])
+    inp = {k: v.cuda() for k, v in make_inputs(case).items()}
+    sigmas = case["sigmas"][:2] if len(case["sigmas"]) > 1 else case["sigmas"] * 2
+    whole = []
+    for slot, sigma in enumerate(sigmas):
+        sig = torch.full((inp["src"].shape[0],), float(sigma), device="cuda")
+        whole.append(cn(inp["src"], x_for(inp, sigma), sig, inp["geometry"], inp.get("cond")))
+        cn.encode(slot, inp["src"], sig, inp["geometry"])
+    for slot, sigma in reversed(list(enumerate(sigmas))):            # both slots were filled before either is read
+        sig = torch.full((inp["src"].shape[0],), float(sigma), device="cuda")
+        b = cn.run_bound(slot, inp["src"], x_for(inp, sigma), sig, inp["geometry"], inp.get("cond"))
+        torch.cuda.synchronize()
+        assert torch.equal(b, whole[slot]), (name, slot)
+        x2 = x_for(inp, sigma) * 0.5                                 # same features, another x: equals a whole evaluation of that x
+        b2 = cn.run_bound(slot, inp["src"], x2, sig, inp["geometry"], inp.get("cond"))
+        assert torch.equal(b2, cn(inp["src"], x2, sig, inp["geometry"], inp.get("cond")))
+
+
 def test_c_net_refuses_missing_inputs():
     from vivid_amd import _lib as L
     case = CASES["tiny_dual"]

@@ -41,6 +41,16 @@ def test_workspace_size_equals_the_python_engines(name, batch):
     assert net.workspace_bytes(batch) == eng.measure_workspace("uncond" if cfg.uncond else "full", batch, has_cond=bool(cfg.super_res))
 
 
+def test_encoder_only_workspace_equals_the_python_engines():
+    cfg, dual = CONFIGS["vivid_base_64"]
+    net = CNet(cfg, dual_source=dual)
+    eng = Engine(cfg, dual_source=dual, precision="bf16x3")
+    assert net._L.vh_net_workspace_bytes_mode(net.handle, CNet.FEATURES, 3) == eng.measure_workspace("features", 3)
+    assert net._L.vh_net_workspace_bytes_mode(net.handle, CNet.BOUND, 3) > 0
+    unc = CNet(vivid_amd.vivid_uncond(64))
+    assert unc._L.vh_net_workspace_bytes_mode(unc.handle, CNet.FEATURES, 1) == 0      # an uncond net has no encoder
+
+
 def test_bad_configurations_are_refused():
     from vivid_amd import _lib as L
     with pytest.raises(L.VividHipError, match="multiples of 32"):

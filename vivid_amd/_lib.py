@@ -176,7 +176,8 @@ CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", 
            "vh_plan_begin", "vh_plan_end", "vh_plan_abort", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
 NET = ["vh_net_create", "vh_net_destroy", "vh_net_num_params", "vh_net_param_info", "vh_net_bind_param", "vh_net_prepared_bytes",
-       "vh_net_prepare", "vh_net_workspace_bytes", "vh_net_record", "vh_net_run"]
+       "vh_net_prepare", "vh_net_workspace_bytes", "vh_net_record", "vh_net_run",
+       "vh_net_workspace_bytes_mode", "vh_net_record_mode", "vh_net_encode", "vh_net_run_bound"]
 
 _lib = None
 
@@ -232,6 +233,11 @@ def lib():
     L.vh_net_workspace_bytes.restype = C.c_size_t
     L.vh_net_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.vh_net_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    L.vh_net_workspace_bytes_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.vh_net_workspace_bytes_mode.restype = C.c_size_t
+    L.vh_net_record_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.vh_net_encode.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
+    L.vh_net_run_bound.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
     _lib = L
     return L
 

@@ -101,6 +101,37 @@ class CNet:
                 t.record_stream(torch.cuda.current_stream(x.device))
         return out
 
+    # -- split evaluation (vh_net_encode / vh_net_run_bound): what vivid_amd.sampler's feature pipeline does, from the C side
+    FULL, FEATURES, BOUND = 0, 1, 2
+
+    def _record(self, mode: int, slot: int, B: int, device):
+        key = (mode, slot, B)
+        if key not in self._ws:
+            nbytes = self._L.vh_net_workspace_bytes_mode(self.handle, mode, B)
+            if nbytes == 0:
+                L.check(-1, "vh_net_workspace_bytes_mode")
+            self._ws[key] = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=device)
+            L.check(self._L.vh_net_record_mode(self.handle, mode, slot, B, C.c_void_p(self._ws[key].data_ptr()), nbytes), "vh_net_record_mode")
+
+    def encode(self, slot: int, src, sigma, geometry):
+        B = src.shape[0] // (2 if self.dual else 1)
+        self._record(self.FEATURES, slot, B, src.device)
+        ts = [t.to(torch.float32).contiguous() for t in (src, sigma, geometry)]
+        self.ctx.set_stream(torch.cuda.current_stream(src.device).cuda_stream)
+        L.check(self._L.vh_net_encode(self.handle, slot, B, *[C.c_void_p(t.data_ptr()) for t in ts]), "vh_net_encode")
+
+    def run_bound(self, slot: int, src, x, sigma, geometry=None, conditioning_image=None) -> torch.Tensor:
+        B = x.shape[0] // (2 if self.dual else 1)
+        self._record(self.FEATURES, slot, B, x.device)
+        self._record(self.BOUND, slot, B, x.device)
+        R = self.cfg.img_resolution
+        out = torch.empty(B, 3, R, R, dtype=torch.float32, device=x.device)
+        ts = [None if t is None else t.to(torch.float32).contiguous() for t in (src, x, sigma, geometry, conditioning_image)]
+        self.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+        L.check(self._L.vh_net_run_bound(self.handle, slot, B, *[None if t is None else C.c_void_p(t.data_ptr()) for t in ts], C.c_void_p(out.data_ptr())),
+                "vh_net_run_bound")
+        return out
+
     def close(self):
         if getattr(self, "handle", None):
             self._L.vh_net_destroy(self.handle)

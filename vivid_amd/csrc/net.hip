@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <tuple>
 
 namespace {
 
@@ -148,15 +149,17 @@ struct Arena {
         free_ = m;
     }
 };
-struct Buf { long long off = -1; long long n = 0; int c = 0; bool ok() const { return off >= 0; } };   // n floats; c = channels (last dim)
+struct Buf { long long off = -1; long long n = 0; int c = 0; float* abs = nullptr; bool ok() const { return off >= 0; } };   // n floats; c = channels (last dim); abs: lives in ANOTHER program's workspace
 
 struct Weight { float* wt = nullptr; size_t off = 0; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0, nj = 0, D = 0, fused_c1 = 0; const float* gain = nullptr; bool has_gain = false; };
 
+struct FeatBuf { Buf f32, s8; };
 struct Program {
-    int B = 0;
+    int B = 0, mode = 0;
     vh_plan* plan = nullptr;
     float* base = nullptr;
     Buf sigma, geometry, src, x, cond, D;
+    std::vector<FeatBuf> feats;       // VH_NET_FEATURES: the encoder's feature list, (fp32, S8) pairs inside this program's workspace
     long long peak_floats = 0;
 };
 
@@ -176,7 +179,7 @@ struct vh_net {
     size_t prepared_floats = 0;
     float* zeros = nullptr; float* scratch_enc = nullptr; float* scratch_unet = nullptr; float* scratch = nullptr;
     bool prepared = false;
-    std::map<int, std::unique_ptr<Program>> programs;
+    std::map<std::tuple<int, int, int>, std::unique_ptr<Program>> programs;      // (mode, slot, batch)
     // walk state
     Arena* A = nullptr; float* base = nullptr; bool emit = false; int rc = VH_OK;
 };
@@ -197,7 +200,7 @@ Buf alloc(vh_net* n, long long rows, long long h, long long w, long long c) {
     return b;
 }
 void release(vh_net* n, Buf& b) { if (b.ok()) { n->A->release(b.off, b.n); b.off = -1; } }
-float* ptr(vh_net* n, const Buf& b) { return b.ok() ? n->base + b.off : nullptr; }
+float* ptr(vh_net* n, const Buf& b) { return !b.ok() ? nullptr : b.abs ? b.abs : n->base + b.off; }
 template <class F, class A> void call(vh_net* n, F fn, const A& a) { if (n->emit && n->rc == VH_OK) n->rc = fn(n->ctx, &a); }
 
 struct ConvOpt {
@@ -237,7 +240,7 @@ std::pair<Buf, Buf> split(vh_net* n, const Buf& s0, float sc0, const Buf* s1, fl
 }
 void mp_sum_coeffs(double t, float& a, float& b) { const double nn = std::sqrt((1.0 - t) * (1.0 - t) + t * t); a = (float)((1.0 - t) / nn); b = (float)(t / nn); }
 
-struct Feat { Buf f32, s8; };
+using Feat = FeatBuf;
 
 // Block.forward :165-206 / XAttnBlock.forward :251-315 (bf16x3 path of engine.Engine._block)
 std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, int rows, const Buf& x, const Buf* skip, const Buf& cvec_all,
@@ -432,17 +435,22 @@ Buf assemble(vh_net* n, const vh_segment* segs, int nseg, int rows, int R, int c
 }
 
 // NVPrecond._forward_dualsource :628-689 / forward :691-749 ("full" when the net has an encoder, "uncond" otherwise)
-void walk(vh_net* n, int B, Program& pr) {
+// mode VH_NET_FULL: encoder (when the net has one) + UNet; VH_NET_FEATURES: encoder only, the features stay in this program's workspace;
+// VH_NET_BOUND: UNet only, reading `ext` = the feature buffers of a VH_NET_FEATURES program in place (the sampler's split evaluation)
+void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext) {
     const vh_net_config& cfg = n->cfg;
     const int R = cfg.img_resolution, nsrc = cfg.dual_source ? 2 : 1, rm = nsrc, rows_all = B * rm;
     const int src_c = 3 + ((cfg.depth_input || cfg.warp_depth_coor) ? 1 : 0);
-    const bool need_enc = n->has_enc;
+    const bool need_enc = n->has_enc && mode != VH_NET_BOUND, need_unet = mode != VH_NET_FEATURES;
+    pr.mode = mode;
     pr.sigma = alloc(n, rows_all, 1, 1, 1);
     pr.geometry = alloc(n, rows_all, 1, 1, cfg.source_label_dim);
     if (need_enc || cfg.warp_depth_coor) pr.src = alloc(n, rows_all, src_c, R, R);
-    pr.x = alloc(n, rows_all, cfg.img_channels, R, R);
-    pr.D = alloc(n, B, cfg.img_channels, R, R);
-    if (cfg.super_res) pr.cond = alloc(n, B, cfg.img_channels, R, R);
+    if (need_unet) {
+        pr.x = alloc(n, rows_all, cfg.img_channels, R, R);
+        pr.D = alloc(n, B, cfg.img_channels, R, R);
+        if (cfg.super_res) pr.cond = alloc(n, B, cfg.img_channels, R, R);
+    }
     Buf sgrid, dgrid;
     if (cfg.warp_depth_coor) {                                    // depth-warp Fourier features :643-652
         sgrid = alloc(n, rows_all, R, R, 128); dgrid = alloc(n, rows_all, R, R, 128);
@@ -471,7 +479,10 @@ void walk(vh_net* n, int B, Program& pr) {
         release(n, cvec);
     }
     release(n, sgrid);
-    {
+    if (mode == VH_NET_FEATURES) pr.feats = feats;
+    if (need_unet) {
+        const bool have_feats = need_enc || ext != nullptr;
+        const std::vector<Feat>* use = ext ? ext : &feats;
         n->scratch = n->scratch_unet;
         vh_segment segs[3]; int ns = 0;
         segs[ns++] = vh_segment{ptr(n, pr.x), 0, cfg.img_channels, cfg.img_channels, rm, 1};
@@ -480,8 +491,8 @@ void walk(vh_net* n, int B, Program& pr) {
         Buf xin = assemble(n, segs, ns, B, R, round_up(n->unet.in_channels, 8), pr.sigma);
         release(n, dgrid);
         Buf cvec = embedding(n, "unet.", n->unet, n->embU, B, pr.sigma, rm, 1.f, pr.geometry, cfg.target_label_dim);
-        const float n_zero = need_enc ? 0.f : (float)nsrc;
-        Buf last = run_unet(n, "unet.", n->unet, n->embU, B, xin, cvec, need_enc ? &feats : nullptr, false, n_zero, nsrc, nullptr);
+        const float n_zero = have_feats ? 0.f : (float)nsrc;
+        Buf last = run_unet(n, "unet.", n->unet, n->embU, B, xin, cvec, have_feats ? use : nullptr, false, n_zero, nsrc, nullptr);
         auto ls8 = split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false);
         Buf F = conv(n, ls8.first, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
         release(n, ls8.first); release(n, last); release(n, cvec);
@@ -685,14 +696,37 @@ extern "C" int vh_net_prepare(vh_net* n, void* buffer, size_t bytes) {
     return VH_OK;
 }
 
-static int net_build(vh_net* n, int B, float* workspace, size_t bytes, Program** out) {
+static int net_build(vh_net* n, int mode, int slot, int B, float* workspace, size_t bytes, Program** out) {
     VH_REQUIRE(B > 0, "vh_net: batch must be positive");
+    VH_REQUIRE(mode >= VH_NET_FULL && mode <= VH_NET_BOUND && (slot == 0 || slot == 1), "vh_net: bad mode / slot");
+    VH_REQUIRE(mode == VH_NET_FULL || n->has_enc, "vh_net: an uncond net has no encoder: only VH_NET_FULL");
     VH_REQUIRE(n->prepared || !workspace, "vh_net_record: call vh_net_prepare after binding the parameters");
     auto pr = std::make_unique<Program>();
     pr->B = B;
+    // the feature list a VH_NET_BOUND walk reads: the recorded VH_NET_FEATURES program of the same (slot, batch), or - for sizing - a dry one
+    std::vector<Feat> ext;
+    if (mode == VH_NET_BOUND) {
+        auto it = n->programs.find(std::make_tuple((int)VH_NET_FEATURES, slot, B));
+        if (workspace) {
+            VH_REQUIRE(it != n->programs.end() && it->second->plan, "vh_net_record: record the VH_NET_FEATURES program of slot %d, batch %d first", slot, B);
+            for (const Feat& f : it->second->feats) {
+                Feat g = f;
+                g.f32.abs = it->second->base + f.f32.off;
+                if (g.s8.ok()) g.s8.abs = it->second->base + f.s8.off;
+                ext.push_back(g);
+            }
+        } else {
+            Arena tmp; Program scratch_prog;
+            n->A = &tmp; n->base = nullptr; n->emit = false; n->rc = VH_OK;
+            walk(n, B, scratch_prog, VH_NET_FEATURES, nullptr);
+            n->A = nullptr;
+            if (n->rc != VH_OK) return n->rc;
+            ext = scratch_prog.feats;
+        }
+    }
     Arena dry;
     n->A = &dry; n->base = nullptr; n->emit = false; n->rc = VH_OK;
-    walk(n, B, *pr);
+    walk(n, B, *pr, mode, mode == VH_NET_BOUND ? &ext : nullptr);
     n->A = nullptr;
     if (n->rc != VH_OK) return n->rc;
     pr->peak_floats = dry.peak;
@@ -703,7 +737,7 @@ static int net_build(vh_net* n, int B, float* workspace, size_t bytes, Program**
     int rc = vh_plan_begin(n->ctx);
     if (rc != VH_OK) return rc;
     n->A = &real; n->base = workspace; n->emit = true; n->rc = VH_OK;
-    walk(n, B, rec);
+    walk(n, B, rec, mode, mode == VH_NET_BOUND ? &ext : nullptr);
     n->A = nullptr; n->emit = false;
     if (n->rc != VH_OK) { (void)vh_plan_abort(n->ctx); return n->rc; }
     rc = vh_plan_end(n->ctx, &rec.plan);
@@ -714,33 +748,35 @@ static int net_build(vh_net* n, int B, float* workspace, size_t bytes, Program**
     return VH_OK;
 }
 
-extern "C" size_t vh_net_workspace_bytes(vh_net* n, int batch) {
+extern "C" size_t vh_net_workspace_bytes_mode(vh_net* n, int mode, int batch) {
     if (!n) return 0;
     Program* p = nullptr;
-    if (net_build(n, batch, nullptr, 0, &p) != VH_OK) return 0;
+    if (net_build(n, mode, 0, batch, nullptr, 0, &p) != VH_OK) return 0;
     const size_t b = (size_t)p->peak_floats * 4;
     delete p;
     return b;
 }
+extern "C" size_t vh_net_workspace_bytes(vh_net* n, int batch) { return vh_net_workspace_bytes_mode(n, VH_NET_FULL, batch); }
 
-extern "C" int vh_net_record(vh_net* n, int batch, void* workspace, size_t bytes) {
+extern "C" int vh_net_record_mode(vh_net* n, int mode, int slot, int batch, void* workspace, size_t bytes) {
     if (!n || !workspace) return vh_fail(VH_EINVAL, "vh_net_record: null argument");
     Program* p = nullptr;
-    const int rc = net_build(n, batch, static_cast<float*>(workspace), bytes, &p);
+    const int rc = net_build(n, mode, slot, batch, static_cast<float*>(workspace), bytes, &p);
     if (rc != VH_OK) return rc;
-    auto it = n->programs.find(batch);
+    const auto key = std::make_tuple(mode, slot, batch);
+    auto it = n->programs.find(key);
     if (it != n->programs.end() && it->second->plan) (void)vh_plan_destroy(it->second->plan);
-    n->programs[batch].reset(p);
+    n->programs[key].reset(p);
     return VH_OK;
 }
+extern "C" int vh_net_record(vh_net* n, int batch, void* workspace, size_t bytes) { return vh_net_record_mode(n, VH_NET_FULL, 0, batch, workspace, bytes); }
 
 // One evaluation: D = net(src, x, sigma, geometry, cond).  All pointers are device fp32, contiguous, in the reference's layouts:
 // src [rows][3 or 4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim] (NULL for an uncond net: zeros),
 // cond [B][3][R][R] (super_res only), out [B][3][R][R]; rows = B * (dual_source ? 2 : 1).
-extern "C" int vh_net_run(vh_net* n, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
-    if (!n || !x || !sigma || !out) return vh_fail(VH_EINVAL, "vh_net_run: null argument");
-    auto it = n->programs.find(batch);
-    VH_REQUIRE(it != n->programs.end() && it->second->plan, "vh_net_run: no program recorded for batch %d (vh_net_record)", batch);
+static int net_run(vh_net* n, int mode, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+    auto it = n->programs.find(std::make_tuple(mode, slot, batch));
+    VH_REQUIRE(it != n->programs.end() && it->second->plan, "vh_net: no program recorded for mode %d, slot %d, batch %d (vh_net_record / vh_net_record_mode)", mode, slot, batch);
     Program& p = *it->second;
     hipStream_t s = n->ctx->stream;
     auto put = [&](const Buf& b, const float* from) -> int {
@@ -748,15 +784,36 @@ extern "C" int vh_net_run(vh_net* n, int batch, const float* src, const float* x
         hipError_t e = from ? hipMemcpyAsync(p.base + b.off, from, (size_t)b.n * 4, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(p.base + b.off, 0, (size_t)b.n * 4, s);
         return e == hipSuccess ? VH_OK : vh_fail(VH_EHIP, "vh_net_run: %s", hipGetErrorString(e));
     };
-    VH_REQUIRE(!p.src.ok() || src, "vh_net_run: this net reads src");
+    VH_REQUIRE(!p.src.ok() || src, "vh_net_run: this program reads src");
     VH_REQUIRE(!p.cond.ok() || cond, "vh_net_run: a super_res net needs the conditioning image (training/models.py:656)");
     VH_REQUIRE(geometry || n->cfg.uncond, "vh_net_run: geometry is required for a conditional net (training/models.py:631)");
+    VH_REQUIRE(!p.x.ok() || (x && out), "vh_net_run: x / out missing");
     int rc;
     if ((rc = put(p.sigma, sigma)) != VH_OK || (rc = put(p.geometry, geometry)) != VH_OK || (rc = put(p.src, src)) != VH_OK ||
         (rc = put(p.x, x)) != VH_OK || (rc = put(p.cond, cond)) != VH_OK) return rc;
     if ((rc = vh_plan_run(n->ctx, p.plan)) != VH_OK) return rc;
+    if (!p.D.ok()) return VH_OK;
     const hipError_t e = hipMemcpyAsync(out, p.base + p.D.off, (size_t)p.D.n * 4, hipMemcpyDeviceToDevice, s);
     return e == hipSuccess ? VH_OK : vh_fail(VH_EHIP, "vh_net_run: %s", hipGetErrorString(e));
+}
+
+// One evaluation: D = net(src, x, sigma, geometry, cond).  All pointers are device fp32, contiguous, in the reference's layouts:
+// src [rows][3 or 4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim] (NULL for an uncond net: zeros),
+// cond [B][3][R][R] (super_res only), out [B][3][R][R]; rows = B * (dual_source ? 2 : 1).
+extern "C" int vh_net_run(vh_net* n, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+    if (!n || !x || !sigma || !out) return vh_fail(VH_EINVAL, "vh_net_run: null argument");
+    return net_run(n, VH_NET_FULL, 0, batch, src, x, sigma, geometry, cond, out);
+}
+// The two halves of an evaluation (training/models.py:664-667 / :676-683): the encoder into feature slot `slot`, and the UNet on that slot's
+// features in place.  The encoder sees (src, sigma, geometry) only, so a sampler can run it for its next noise level on another stream
+// (vh_ctx_set_stream between the calls) and once per level instead of once per call (vivid_amd/sampler.py does exactly this from Python).
+extern "C" int vh_net_encode(vh_net* n, int slot, int batch, const float* src, const float* sigma, const float* geometry) {
+    if (!n || !src || !sigma) return vh_fail(VH_EINVAL, "vh_net_encode: null argument");
+    return net_run(n, VH_NET_FEATURES, slot, batch, src, nullptr, sigma, geometry, nullptr, nullptr);
+}
+extern "C" int vh_net_run_bound(vh_net* n, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+    if (!n || !x || !sigma || !out) return vh_fail(VH_EINVAL, "vh_net_run_bound: null argument");
+    return net_run(n, VH_NET_BOUND, slot, batch, src, x, sigma, geometry, cond, out);
 }
 
 extern "C" int vh_net_destroy(vh_net* n) {
