@@ -499,7 +499,9 @@ int vh_net_run(vh_net* net, int batch, const float* src, const float* x, const f
  *                    other is read);
  *   VH_NET_BOUND     UNet only, reading the features of the VH_NET_FEATURES program of the same (slot, batch) in place - record that
  *                    one first.  `src` is read only by warp_depth_coor nets (may be NULL otherwise).
- * vh_net_encode + vh_net_run_bound == vh_net_run, bit for bit. */
+ * vh_net_encode + vh_net_run_bound == vh_net_run, bit for bit.  The two VH_NET_BOUND programs of a batch size may be recorded over the SAME
+ * workspace (they are replayed one after the other and differ only in the feature pointers they read); the two VH_NET_FEATURES programs
+ * need one each. */
 enum { VH_NET_FULL = 0, VH_NET_FEATURES = 1, VH_NET_BOUND = 2 };
 size_t vh_net_workspace_bytes_mode(vh_net* net, int mode, int batch);
 int vh_net_record_mode(vh_net* net, int mode, int slot, int batch, void* workspace, size_t bytes);

@@ -134,6 +134,31 @@ def test_sampler_feature_pipeline_changes_nothing(name, extra, monkeypatch):
     assert torch.equal(a, b)
 
 
+def test_split_evaluation_handles_are_validated_and_equal_the_whole_call():
+    """NVPrecond.encode_features + forward(inject_features=handle) == forward (training/models.py:664-683), for both feature slots;
+    a handle is refused by another net, after the weights changed, and an uncond net has no encoder to run."""
+    import vivid_amd
+    case = CASES["tiny_guided"]
+    net, other, gnet = _net(case["cfg"], case["seed"]), _net(case["cfg"], case["seed"]), _net(case["gcfg"], case["seed"] + 1)
+    inp = _cuda(make_inputs(case))
+    sig = torch.full((inp["src"].shape[0],), 0.7, device="cuda")
+    x = x_for(inp, 0.7)
+    whole = net(inp["src"], x, sig, inp["geometry"])
+    for slot in (0, 1, 0):
+        h = net.encode_features(inp["src"], sig, inp["geometry"], slot=slot)
+        assert torch.equal(net(inp["src"], x, sig, inp["geometry"], inject_features=h), whole)
+    feats = net(inp["src"], x, sig, inp["geometry"], return_features=True)
+    via_handle = net(inp["src"], x, sig, inp["geometry"], return_features=True, inject_features=h)
+    assert all(torch.equal(a, b) for a, b in zip(feats, via_handle))
+    with pytest.raises(ValueError, match="another net"):
+        other(inp["src"], x, sig, inp["geometry"], inject_features=h)
+    with pytest.raises(RuntimeError, match="no encoder"):
+        gnet.encode_features(inp["src"], sig, inp["geometry"])
+    net.load_state_dict(vivid_amd.synth_state_dict(case["cfg"], seed=99))
+    with pytest.raises(ValueError, match="weight version"):
+        net(inp["src"], x, sig, inp["geometry"], inject_features=h)
+
+
 def test_uncond_closed_form_equals_zero_features():
     """The n_zero_keys closed form must equal running attention over explicit zero features."""
     case = CASES["tiny_guided"]

@@ -672,7 +672,13 @@ class Engine:
             self._backing = None
             if emit:
                 self.oplog = []
-                self._backing = torch.empty(peak, dtype=torch.float32, device=self.device)
+                # the two 'bound' programs of a batch size differ only in the feature pointers they read and never run at the same time
+                # (both are replayed on the caller's stream): they share one workspace
+                twin = self.programs.get((mode, B, has_cond, want_logvar, slot ^ 1)) if mode == "bound" else None
+                if twin is not None and twin.backing.numel() >= peak:
+                    self._backing = twin.backing
+                else:
+                    self._backing = torch.empty(peak, dtype=torch.float32, device=self.device)
                 self._A.base_ptr = self._backing.data_ptr()
                 if self.hook is None:
                     self.ctx.plan_begin()
