@@ -56,7 +56,8 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * "attn_pipe": 1 (default) software-pipelined bf16x3 attention kernels for long sequences, 0 the plain ones;
  * "attn_nomax": 1 (default) bounded-logit attention keeps no running maximum, 0 keeps it;
  * "conv_slim2": -1 (default) Cout <= 64 layers at large M take the 256x64 tile (two workgroups per CU), 0 the 512x64 one;
- * "conv_korder_mb": input size in MB above which 3x3 convolutions take the chunk-major K order (default: see conv_x3.hip).
+ * "conv_korder_mb": input size in MB above which 3x3 convolutions take the chunk-major K order (default: see conv_x3.hip);
+ * "conv_ksplit": > 0 forces that many K slices where split-K is possible (default 0: the dispatcher's rule).
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);
 

@@ -17,7 +17,7 @@ import torch  # noqa: E402
 from vivid_amd import _lib as L  # noqa: E402
 
 
-KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60}
+KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0}
 
 
 def load(suffix):

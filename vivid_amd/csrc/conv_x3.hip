@@ -649,11 +649,16 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         double best = 1e30;
         for (int ks = 1; ks <= smax; ++ks) {
             if ((size_t)ks * (size_t)M * a.cout > a.scratch_floats) break;
+            // time ~ rounds of 256 workgroups x (K-tiles per slice + the tile's fixed prologue / epilogue, worth ~14 K-tiles) + a charge per slice for
+            // the partial slabs (fitted to profiles/r03_ab_conv_ksplit_rule.txt; without the fixed term 96 tiles took 5 slices in two rounds
+            // where 2 slices in one round are 10 % faster)
             const double rounds = (double)((MT * NT * ks + 255) / 256);
-            const double cost = rounds / ks + 0.01 * (ks - 1);
+            const double cost = rounds * (1.0 / ks + 14.0 / KTall) + 0.01 * (ks - 1);
             if (cost < best - 1e-9) { best = cost; ksplit = ks; }
         }
     }
+    if (const int forced = vh_knob(VH_KNOB_CONV_KSPLIT); forced > 0 && a.scratch && a.epi != VH_EPI_QKV &&
+        (size_t)forced * (size_t)M * a.cout <= a.scratch_floats && forced <= KTall) ksplit = forced;      // A/B runs only
     k.ksplit = ksplit;
     k.scratch = a.scratch;
     k.dbg = vh_debug_ptr();

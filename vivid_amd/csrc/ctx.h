@@ -47,7 +47,8 @@ enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATT
        VH_KNOB_ATTN_NOMAX = 7,       // 0: keep the running maximum although logit_bound allows dropping it
        VH_KNOB_CONV_SLIM2 = 8,       // -1 (default): Cout <= 64 layers take the 256x64 two-per-CU tile; 0: the 512x64 one (A/B runs)
        VH_KNOB_CONV_KORDER_MB = 9,   // input size (MB) above which 3x3 convolutions take the chunk-major K order (default 60)
-       VH_NUM_KNOBS = 10 };
+       VH_KNOB_CONV_KSPLIT = 10,     // > 0: force this many K slices in the glds convolutions (A/B runs of the split-K rule)
+       VH_NUM_KNOBS = 11 };
 int vh_knob(int id);
 // device buffer for the stamps of diagnostic builds (-DVH_CLOCK), set through the knobs "dbg_lo"/"dbg_hi"; null otherwise
 inline unsigned long long* vh_debug_ptr() {
