@@ -2,10 +2,12 @@
 """Interleaved A/B timing of library builds / knob settings on one device, in one process (cdna guide 5.4 rule 24).
 
   python tools/ab.py attn  B HEADS S KL [D]            -- vh_attention_x3 as the engine calls it (bounded logits)
-  python tools/ab.py conv  ROWS H W CIN COUT [TAPS] [EPI]  -- vh_conv, glds kernel (EPI 0 store, 2 residual mp_sum)
+  python tools/ab.py conv  ROWS H W CIN COUT [TAPS] [EPI]  -- vh_conv, glds kernel (EPI 0 store, 1 cvec + silu, 2 residual mp_sum, 3 the q/k/v
+                                                           epilogue of attn_qkv: COUT = 3 * heads * 64, self keys only)
 Variants come from VARIANTS="name=lib[:knob=val[,knob=val]];..." where lib is a suffix of vivid_amd/libvivid_hip[_<suffix>].so
 ("" = the product build), e.g.  VARIANTS="base=;dyn=attn_dyn;noxcd=:attn_xcd=0".
 Prints median and min ms per launch over ROUNDS (default 7) interleaved rounds of N (default 10) launches."""
+import ctypes as ct
 import math
 import os
 import statistics
@@ -77,6 +79,7 @@ def main():
         flops = 2.0 * M * cout * cin * taps
         res = torch.randn(M, cout, generator=g).cuda() if epi == 2 else None
         cvec = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda() if epi == 1 else None
+        heads, S = cout // 192, h * w
         for name, lib, knobs in parse_variants():
             ctx = load(lib)
             s8 = torch.empty(M * cin, device="cuda")
@@ -85,15 +88,21 @@ def main():
             ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin, k_pad=k_pad, gain_ptr=None,
                                                         gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2))
             out = torch.empty(M, cout, device="cuda")
+            qkv = None
+            if epi == 3:
+                Q, K, V = (torch.zeros(rows * heads * S * 64, device="cuda") for _ in range(3))
+                qkv = L.QkvEpilogue(q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), heads=heads, nj=3, rows_per_b=1, koff=0, kl=S, qscale=0.18)
+                out = torch.cat([Q, K, V])                  # (a copy: the comparison below is then trivially 0; timing only)
             s8mode = knobs.pop("s8", 0)                     # 0: fp32 output, 1: S8 only, 2: both
             o8 = torch.empty(M * cout, device="cuda") if s8mode else None
             a = L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=taps, pro=0,
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
-                           scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if s8mode != 1 else None, out_s8=o8.data_ptr() if o8 is not None else None,
+                           scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if (s8mode != 1 and epi != 3) else None, out_s8=o8.data_ptr() if o8 is not None else None,
                            out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,
                            cvec=cvec.data_ptr() if cvec is not None else None, cvec_ld=cout if cvec is not None else 0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
-                           korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0))
-            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, o8 if s8mode == 1 else out)))
+                           korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0),
+                           qkv=ct.addressof(qkv) if qkv is not None else None)
+            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, qkv, (Q, K, V) if epi == 3 else None, o8 if s8mode == 1 else out)))
 
     def launch(r, k):
         name, ctx, op, a, knobs, _ = r

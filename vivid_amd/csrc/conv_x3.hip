@@ -68,6 +68,22 @@ __device__ __forceinline__ void wait_dma() {
 // TAIL = true: the K loop continues, after the nine taps, over a 1-tap segment read from a second S8 source (vh_conv_args.src1: conv_res1 +
 // conv_skip of a decoder block as one GEMM).  A template parameter so that the plain instantiations keep their register allocation (the
 // 512x128 tile sits 2-20 registers under the limit); the tail's pointers are derived from state that is live in the loop anyway.
+// (a, b) -> packed bf16 hi pair and lo pair of the hi + lo split: one v_cvt_pk_bf16_f32 per pair (the same round-to-nearest-even values as two
+// bf16_rn_bits calls each, without their shifts and ors)
+__device__ __forceinline__ void bf16_split_pair(float a, float b, unsigned& H, unsigned& L) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    H = __builtin_bit_cast(unsigned, h);
+    bf16x2_t q; q[0] = (__bf16)(a - __uint_as_float(H << 16)); q[1] = (__bf16)(b - __uint_as_float(H & 0xFFFF0000u));
+    L = __builtin_bit_cast(unsigned, q);
+}
+
+// x as seen through a DPP control word (quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140): lanes exchange inside their row of 16
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
 template <int TAPS, int WAVES_M, int WAVES_N, int MI, int NI, bool M16, bool CHUNK, int OCC = 2, bool TAIL = false>
 __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
     static_assert(!TAIL || TAPS == 9, "the tail segment exists for 3x3 convolutions only");
@@ -397,7 +413,9 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
         if (a.epi == VH_EPI_QKV) {
             // Fused q/k/v split (see VH_EPI_QKV in vivid_hip.h).  With 64-channel heads this wave's 64 accumulator columns are one
             // (head, j); with 32-channel heads (the super-resolution UNet) each 32-column half is one.
-            const int colw = n0 + wn * 64;
+            // (wave coordinates through one readfirstlane: the block / head / key arithmetic below then runs on the scalar unit)
+            const int wq = __builtin_amdgcn_readfirstlane(w), wms = wq / WAVES_N, wns = wq % WAVES_N;
+            const int colw = n0 + wns * 64;
             if (colw >= a.cout) return;
             const int D = a.q_d;
             const float rsd = D == 64 ? 0.125f : 0.17677669529663687f;            // 1/sqrt(D)
@@ -414,14 +432,18 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
             auto normalise_rows = [&](f32x4& t0, f32x4& t1, f32x4& t2, f32x4& t3) __attribute__((always_inline)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    // the 16 lanes of a row are one DPP row: pairs, quads (quad_perm), halves (row_half_mirror), the row (row_mirror) -
+                    // the same sum tree as an xor butterfly, one v_add_f32 with a DPP operand per step instead of an LDS round trip
                     float s0 = t0[r] * t0[r] + t1[r] * t1[r], s1 = t2[r] * t2[r] + t3[r] * t3[r];
-                    s0 += __shfl_xor(s0, 1); s1 += __shfl_xor(s1, 1);
-                    s0 += __shfl_xor(s0, 2); s1 += __shfl_xor(s1, 2);
-                    s0 += __shfl_xor(s0, 4); s1 += __shfl_xor(s1, 4);
-                    s0 += __shfl_xor(s0, 8); s1 += __shfl_xor(s1, 8);
+                    s0 += dpp_f32<0xB1>(s0); s1 += dpp_f32<0xB1>(s1);
+                    s0 += dpp_f32<0x4E>(s0); s1 += dpp_f32<0x4E>(s1);
+                    s0 += dpp_f32<0x141>(s0); s1 += dpp_f32<0x141>(s1);
+                    s0 += dpp_f32<0x140>(s0); s1 += dpp_f32<0x140>(s1);
                     if (D == 64) s0 = s1 = s0 + s1;
-                    const float c0 = ((a.q_nj == 3 && j_[0] == 0) ? a.q_scale : 1.f) / (1e-4f + sqrtf(s0) * rsd);
-                    const float c1 = ((a.q_nj == 3 && j_[1] == 0) ? a.q_scale : 1.f) / (1e-4f + sqrtf(s1) * rsd);
+                    // v_sqrt_f32 / v_rcp_f32 (1 ulp each) instead of the IEEE sequences: a 1e-7 relative change in a scale that the
+                    // tests hold to 2e-6 against vh_qkv_split_x3, and ~50 fewer instructions per row in an issue-bound epilogue
+                    const float c0 = ((a.q_nj == 3 && j_[0] == 0) ? a.q_scale : 1.f) * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_sqrtf(s0), rsd, 1e-4f));
+                    const float c1 = ((a.q_nj == 3 && j_[1] == 0) ? a.q_scale : 1.f) * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_sqrtf(s1), rsd, 1e-4f));
                     t0[r] *= c0; t1[r] *= c0; t2[r] *= c1; t3[r] *= c1;
                 }
             };
@@ -433,7 +455,7 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
                 normalise_rows(acc16[2 * mi + 1][0], acc16[2 * mi + 1][1], acc16[2 * mi + 1][2], acc16[2 * mi + 1][3]);
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int row0 = m0 + (wm * MI + mi) * 32;
+                    const int row0 = m0 + (wms * MI + mi) * 32;
                     if (row0 >= a.M) continue;                              // (M % 32 == 0: blocks are all-in or all-out)
                     if (colw + ni * 32 >= a.cout) continue;                  // (32-channel heads: cout need not fill the wave's 64 columns)
                     const int head = head_[ni], j = j_[ni];
@@ -455,25 +477,22 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
                                 patch[(16 + rb + r) * LD + 16 + c] = acc16[2 * mi + 1][2 * ni + 1][r];
                             }
                         }
+                        // one 64-bit address per lane and block (scalar block part + this lane's row / channel); the four row groups follow at 8 rows
                         const int cg = l & 7, rsub = l >> 3;
+                        const int d0 = dbase + 4 * cg;
+                        float* qp = a.q + (bhq * S + s0) * D + (rsub * D + d0);
+                        unsigned short* kp = a.qk + (bhq * a.q_klp + key0) * D * 2 + ((rsub * D + (d0 & ~7)) * 2 + (d0 & 7));
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const int rl = rsub + 8 * i;
-                            const float4 v = *reinterpret_cast<const float4*>(&patch[rl * LD + 4 * cg]);
-                            const int d0 = dbase + 4 * cg;
+                            const float4 v = *reinterpret_cast<const float4*>(&patch[(rsub + 8 * i) * LD + 4 * cg]);
                             if (is_q) {
-                                *reinterpret_cast<float4*>(a.q + (bhq * S + s0 + rl) * D + d0) = v;
+                                *reinterpret_cast<float4*>(qp + 8 * i * D) = v;
                             } else {
-                                const float y[4] = {v.x, v.y, v.z, v.w};
-                                unsigned h[4], lo[4];
-#pragma unroll
-                                for (int e2 = 0; e2 < 4; ++e2) {
-                                    h[e2] = bf16_rn_bits(y[e2]);
-                                    lo[e2] = bf16_rn_bits(y[e2] - __uint_as_float(h[e2] << 16));
-                                }
-                                unsigned short* kp = a.qk + ((bhq * a.q_klp + key0 + rl) * D + (d0 & ~7)) * 2 + (d0 & 7);
-                                *reinterpret_cast<uint2*>(kp) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                                *reinterpret_cast<uint2*>(kp + 8) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                                unsigned H0, H1, L0, L1;
+                                bf16_split_pair(v.x, v.y, H0, L0);
+                                bf16_split_pair(v.z, v.w, H1, L1);
+                                *reinterpret_cast<uint2*>(kp + 16 * i * D) = make_uint2(H0, H1);
+                                *reinterpret_cast<uint2*>(kp + 16 * i * D + 8) = make_uint2(L0, L1);
                             }
                         }
                     } else {
@@ -482,21 +501,19 @@ __global__ __launch_bounds__(512, OCC) void conv_x3_glds(const ConvK a) {
                         // q = lane>>4) of one channel (column lane&15), and the permutation keeps those four together at positions
                         // 4*((q&1)*2 + (q>>1)) - one 8-byte store per tile and half, no LDS transpose.
                         const int q4 = l >> 4, qs = ((q4 & 1) << 1) | (q4 >> 1);
+                        const size_t klp = (size_t)a.q_klp;
+                        unsigned short* vb = a.qv + (bhq * D + dbase) * 2 * klp + key0 + ((size_t)((l & 15) * 2) * klp + 4 * qs);     // (scalar block part + lane part)
 #pragma unroll
                         for (int ta = 0; ta < 2; ++ta)
 #pragma unroll
                             for (int tb = 0; tb < 2; ++tb) {
                                 const f32x4 tv = acc16[2 * mi + ta][2 * ni + tb];
-                                unsigned h[4], lo[4];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    h[r] = bf16_rn_bits(tv[r]);
-                                    lo[r] = bf16_rn_bits(tv[r] - __uint_as_float(h[r] << 16));
-                                }
-                                const int d = dbase + 16 * tb + (l & 15);
-                                unsigned short* vp = a.qv + ((bhq * D + d) * 2) * (size_t)a.q_klp + key0 + 16 * ta + 4 * qs;
-                                *reinterpret_cast<uint2*>(vp) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                                *reinterpret_cast<uint2*>(vp + a.q_klp) = make_uint2(lo[0] | (lo[1] << 16), lo[2] | (lo[3] << 16));
+                                unsigned H0, H1, L0, L1;
+                                bf16_split_pair(tv[0], tv[1], H0, L0);
+                                bf16_split_pair(tv[2], tv[3], H1, L1);
+                                unsigned short* vp = vb + (size_t)(32 * tb) * klp + 16 * ta;      // channel dbase + 16*tb + (l & 15), keys key0 + 16*ta + 4*qs
+                                *reinterpret_cast<uint2*>(vp) = make_uint2(H0, H1);
+                                *reinterpret_cast<uint2*>(vp + klp) = make_uint2(L0, L1);
                             }
                     }
                 }
