@@ -2,6 +2,7 @@
 """Interleaved A/B timing of library builds / knob settings on one device, in one process (cdna guide 5.4 rule 24).
 
   python tools/ab.py attn  B HEADS S KL [D]            -- vh_attention_x3 as the engine calls it (bounded logits)
+  python tools/ab.py split ROWS H W C0 C1 RAW          -- vh_split (concat + silu -> S8; RAW 1: also the raw S8 form); "TF/s" column = GB/s
   python tools/ab.py conv  ROWS H W CIN COUT [TAPS] [EPI]  -- vh_conv, glds kernel (EPI 0 store, 1 cvec + silu, 2 residual mp_sum, 3 the q/k/v
                                                            epilogue of attn_qkv: COUT = 3 * heads * 64, self keys only)
 Variants come from VARIANTS="name=lib[:knob=val[,knob=val]];..." where lib is a suffix of vivid_amd/libvivid_hip[_<suffix>].so
@@ -67,6 +68,19 @@ def main():
             a = L.AttentionArgs(q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), b=b, heads=heads, s=S, kl=KL, d=D, n_zero_keys=0.0, out=out.data_ptr(),
                                 out_s8=0, logit_bound=1.4426950408889634 * math.sqrt(D) * 1.001)
             runs.append((name, ctx, "vh_attention_x3", a, knobs, (Q, K, V, out)))
+    elif kind == "split":                                  # ROWS H W C0 C1 RAW: the decoder's concat + silu -> S8 (+ raw S8 for the fused skip tail)
+        rows, h, w, c0, c1, raw = args[:6]
+        M, cp = rows * h * w, (c0 + c1 + 31) // 32 * 32
+        x0 = torch.randn(M, c0, generator=g).cuda()
+        x1 = torch.randn(M, c1, generator=g).cuda() if c1 else None
+        flops = 4.0 * M * (c0 + c1 + cp * (2 if raw else 1)) * 1e3   # printed as "TF/s": read it as GB/s
+        for name, lib, knobs in parse_variants():
+            ctx = load(lib)
+            o = torch.empty(M * cp, device="cuda")
+            r = torch.empty(M * cp, device="cuda") if raw else None
+            a = L.SplitArgs(src0=x0.data_ptr(), src1=x1.data_ptr() if c1 else None, c0=c0, c1=c1, scale0=0.8, scale1=1.1, pro=1, npix=M, c_pad=cp,
+                            out=o.data_ptr(), out_raw=r.data_ptr() if raw else None)
+            runs.append((name, ctx, "vh_split", a, knobs, (x0, x1, r, o)))
     else:
         rows, h, w, cin, cout = args[:5]
         taps = args[5] if len(args) > 5 else 9

@@ -35,6 +35,23 @@ __device__ __forceinline__ void split_bf16(float v, unsigned& hi, unsigned& lo) 
     lo = bf16_rn_bits(v - __uint_as_float(hi << 16));
 }
 
+// (a, b) -> packed bf16 hi pair and lo pair: one v_cvt_pk_bf16_f32 per pair, the same values as two split_bf16 calls
+__device__ __forceinline__ void split_bf16_pair(float a, float b, unsigned& H, unsigned& L) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    H = __builtin_bit_cast(unsigned, h);
+    bf16x2_t q; q[0] = (__bf16)(a - __uint_as_float(H << 16)); q[1] = (__bf16)(b - __uint_as_float(H & 0xFFFF0000u));
+    L = __builtin_bit_cast(unsigned, q);
+}
+// 8 values -> the 32-byte S8 chunk [hi x8 | lo x8]
+__device__ __forceinline__ void store_s8_chunk(uint4* o, const float (&e)[8]) {
+    unsigned H[4], L[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_bf16_pair(e[2 * j], e[2 * j + 1], H[j], L[j]);
+    o[0] = make_uint4(H[0], H[1], H[2], H[3]);
+    o[1] = make_uint4(L[0], L[1], L[2], L[3]);
+}
+
 // ---------------------------------------------------------------- weight prep
 __global__ __launch_bounds__(256) void prep_weight_k(vh_prep_weight_args a) {
     __shared__ float red[4];
@@ -217,11 +234,13 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
 
 // ---------------------------------------------------------------- fp32 -> S8 split (+concat, scale, silu)
 // one thread per 8-channel chunk of one pixel
-__global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total) {
+__global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total, unsigned div_mul, unsigned div_shr) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int nch = a.c_pad >> 3;
-    const long long pix = i / nch;
+    // chunk index -> (pixel, chunk of the pixel): a multiply-high when the index fits 31 bits (every launch of the networks here), the
+    // 64-bit division otherwise
+    const long long pix = div_mul ? (long long)(__umulhi((unsigned)i, div_mul) >> div_shr) : i / nch;
     const int c = (int)(i - pix * nch) * 8;
     float v[8];
 #pragma unroll
@@ -234,24 +253,15 @@ __global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total)
         const float4 p0 = *reinterpret_cast<const float4*>(sp), p1 = *reinterpret_cast<const float4*>(sp + 4);
         v[0] = p0.x; v[1] = p0.y; v[2] = p0.z; v[3] = p0.w; v[4] = p1.x; v[5] = p1.y; v[6] = p1.z; v[7] = p1.w;
     }
-    unsigned h[8], l[8];
-    if (a.out_raw) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) split_bf16(v[j] * sc, h[j], l[j]);
-        uint4* o = reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out_raw) + (size_t)i * 16);
-        o[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-        o[1] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
-    }
+    for (int j = 0; j < 8; ++j) v[j] *= sc;
+    if (a.out_raw) store_s8_chunk(reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out_raw) + (size_t)i * 16), v);
     if (!a.out) return;
+    if (a.pro == VH_PRO_SILU) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float e = v[j] * sc;
-        if (a.pro == VH_PRO_SILU) e = mp_silu_dev(e);
-        split_bf16(e, h[j], l[j]);
+        for (int j = 0; j < 8; ++j) v[j] = mp_silu_dev(v[j]);
     }
-    uint4* o = reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out) + (size_t)i * 16);
-    o[0] = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    o[1] = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    store_s8_chunk(reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out) + (size_t)i * 16), v);
 }
 
 // ---------------------------------------------------------------- q/k/v split + head norm
@@ -594,7 +604,15 @@ extern "C" int vh_split(vh_ctx* ctx, const vh_split_args* p) {
     VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.out) && vh_aligned16(a.out_raw), "vh_split: pointers must be 16-byte aligned");
     const long long total = a.npix * (a.c_pad / 8);
     return vh_dispatch(ctx, VH_TAG_SPLIT, 0.0, 4.0 * (double)a.npix * ((double)a.c0 + a.c1 + a.c_pad * ((a.out ? 1 : 0) + (a.out_raw ? 1 : 0))), [a, total](hipStream_t s) -> int {
-        hipLaunchKernelGGL(split_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total);
+        // magic numbers of n / (c_pad / 8) for 0 <= n < 2^31 (as conv_common.h's FastDiv); 0 = take the division
+        unsigned mul = 0, shr = 0;
+        const unsigned d = (unsigned)(a.c_pad / 8);
+        if (total < (1ll << 31)) {                     // (d >= 4: c_pad is a multiple of 32)
+            unsigned l = 0;
+            while ((1ull << l) < d) ++l;
+            mul = (unsigned)(((1ull << (31 + l)) / d) + 1); shr = l - 1;
+        }
+        hipLaunchKernelGGL(split_k, dim3(blocks_for(total, 256)), dim3(256), 0, s, a, total, mul, shr);
         return vh_check_launch("split_k");
     });
 }
