@@ -21,5 +21,5 @@ python3 tools/op_profile.py --res 256 --batch 16 > profiles/${TAG%%_c2*}_layers_
 python3 tools/op_profile.py --res 256 --batch 16 --uncond > profiles/${TAG%%_c2*}_layers_c2_gnet.txt 2>/dev/null
 python3 tools/op_profile.py --res 1024 --batch 4 --sr > profiles/${TAG%%_c2*}_layers_c4_sr1024_b4.txt 2>/dev/null
 python3 tools/op_profile.py --res 256 --batch 16 --warp > profiles/${TAG%%_c2*}_layers_c5_warp.txt 2>/dev/null
-mkdir -p gpurun_out/profiles_new && cp profiles/${TAG}* profiles/${TAG%%_c2*}_layers_* gpurun_out/profiles_new/
+rm -rf gpurun_out/profiles_new && mkdir -p gpurun_out/profiles_new && cp profiles/${TAG}* profiles/${TAG%%_c2*}_layers_* gpurun_out/profiles_new/
 tail -30 $OUT/summary.txt
