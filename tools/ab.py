@@ -2,6 +2,7 @@
 """Interleaved A/B timing of library builds / knob settings on one device, in one process (cdna guide 5.4 rule 24).
 
   python tools/ab.py attn  B HEADS S KL [D]            -- vh_attention_x3 as the engine calls it (bounded logits)
+  python tools/ab.py pixnorm ROWS H W C                -- vh_pixnorm (scale + S8 of silu(normalised x)); "TF/s" column = GB/s
   python tools/ab.py split ROWS H W C0 C1 RAW          -- vh_split (concat + silu -> S8; RAW 1: also the raw S8 form); "TF/s" column = GB/s
   python tools/ab.py conv  ROWS H W CIN COUT [TAPS] [EPI]  -- vh_conv, glds kernel (EPI 0 store, 1 cvec + silu, 2 residual mp_sum, 3 the q/k/v
                                                            epilogue of attn_qkv: COUT = 3 * heads * 64, self keys only)
@@ -81,6 +82,17 @@ def main():
             a = L.SplitArgs(src0=x0.data_ptr(), src1=x1.data_ptr() if c1 else None, c0=c0, c1=c1, scale0=0.8, scale1=1.1, pro=1, npix=M, c_pad=cp,
                             out=o.data_ptr(), out_raw=r.data_ptr() if raw else None)
             runs.append((name, ctx, "vh_split", a, knobs, (x0, x1, r, o)))
+    elif kind == "pixnorm":                                # ROWS H W C: x -> per-pixel scale + S8 of silu(normalised x), as the encoder blocks call it
+        rows, h, w, c = args[:4]
+        M = rows * h * w
+        x = torch.randn(M, c, generator=g).cuda()
+        flops = 8.0 * M * c * 1e3                           # printed as "TF/s": read it as GB/s
+        for name, lib, knobs in parse_variants():
+            ctx = load(lib)
+            o = torch.empty(M * c, device="cuda")
+            sc = torch.empty(M, device="cuda")
+            a = L.PixnormArgs(inp=x.data_ptr(), out=None, rows=rows, h=h, w=w, c=c, pool=0, norm=1, out_s8=o.data_ptr(), scale_out=sc.data_ptr())
+            runs.append((name, ctx, "vh_pixnorm", a, knobs, (x, sc, o)))
     else:
         rows, h, w, cin, cout = args[:5]
         taps = args[5] if len(args) > 5 else 9

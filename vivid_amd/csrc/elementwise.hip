@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void pixnorm_k(vh_pixnorm_args a, long long np
         float ss = 0.f;
         for (int i = lane; i < c4; i += 64) {
             const float4 v = fetch(i);
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            ss = fmaf(v.w, v.w, fmaf(v.z, v.z, fmaf(v.y, v.y, fmaf(v.x, v.x, ss))));
         }
         ss = wave_sum(ss);
         scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
         if (a.norm) {
             float ss = 0.f;
 #pragma unroll
-            for (int n = 0; n < NV; ++n) ss += v[q][n].x * v[q][n].x + v[q][n].y * v[q][n].y + v[q][n].z * v[q][n].z + v[q][n].w * v[q][n].w;
+            for (int n = 0; n < NV; ++n)       // explicit fma chain: the sum does not depend on what the compiler chooses to contract in this build
+                ss = fmaf(v[q][n].w, v[q][n].w, fmaf(v[q][n].z, v[q][n].z, fmaf(v[q][n].y, v[q][n].y, fmaf(v[q][n].x, v[q][n].x, ss))));
 #pragma unroll
             for (int o = LPP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
             scale = 1.0f / (1e-4f + sqrtf(ss) * rsqrtf((float)a.c));
@@ -220,13 +221,17 @@ __global__ __launch_bounds__(256) void pixnorm_reg_k(vh_pixnorm_args a, long lon
             t.x *= scale; t.y *= scale; t.z *= scale; t.w *= scale;
             if (dst) dst[i] = t;
             if (s8) {
-                const float e[4] = {mp_silu_dev(t.x), mp_silu_dev(t.y), mp_silu_dev(t.z), mp_silu_dev(t.w)};
-                unsigned h[4], l[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) split_bf16(e[j], h[j], l[j]);
-                unsigned short* qd = s8 + (size_t)(i >> 1) * 16 + (i & 1) * 4;
-                *reinterpret_cast<uint2*>(qd) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-                *reinterpret_cast<uint2*>(qd + 8) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+                // this float4 is one half of an 8-channel chunk [hi x8 | lo x8] and the lane next door (li ^ 1, same pixel: LPP and c/4 are
+                // even) holds the other: the pair swaps one 8-byte piece through DPP (quad_perm [1,0,3,2]) so that the even lane writes the
+                // hi half and the odd lane the lo half - one 16-byte store per lane instead of two 8-byte ones
+                unsigned H0, H1, L0, L1;
+                split_bf16_pair(mp_silu_dev(t.x), mp_silu_dev(t.y), H0, L0);
+                split_bf16_pair(mp_silu_dev(t.z), mp_silu_dev(t.w), H1, L1);
+                const bool odd = i & 1;
+                const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? H0 : L0), 0xB1, 0xF, 0xF, true);
+                const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? H1 : L1), 0xB1, 0xF, 0xF, true);
+                unsigned short* qd = s8 + (size_t)(i >> 1) * 16 + (odd ? 8 : 0);
+                *reinterpret_cast<uint4*>(qd) = odd ? make_uint4(r0, r1, L0, L1) : make_uint4(H0, H1, r0, r1);
             }
         }
     }
