@@ -183,11 +183,11 @@ typedef struct {
     int tile;                              /* VH_CONV_GLDS256: workgroup tile, VH_TILE_AUTO (by shape and grid size) or a forced shape
                                               (pixels x output channels): VH_TILE_256x128, VH_TILE_256x256 (needs cout % 256 == 0),
                                               VH_TILE_512x128, VH_TILE_512x64 and VH_TILE_256x64 (need cout <= 64; the latter runs two
-                                              workgroups per CU).  A forced shape disables split-K unless
+                                              workgroups per CU), VH_TILE_256x192 (3x3 only).  A forced shape disables split-K unless
                                               the grid is small; every shape computes the same sums in the same order. */
 } vh_conv_args;
 enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
-enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5 };
+enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5, VH_TILE_256x192 = 7 };
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
 
 /* ---- K6 (+K9): pixel norm with optional 2x2 mean pooling ------------------

@@ -170,7 +170,7 @@ def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("korder", [1, 2])                  # VH_KORDER_TAP, VH_KORDER_CHUNK
-@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU)
+@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32), (7, 192), (7, 96), (7, 384)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU), 256x192 (+ ragged N, two N-tiles)
 def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
     """Every workgroup tile of conv_x3_glds with both K orders and every epilogue, forced through vh_conv_args.tile / .korder on a
     small ragged problem, against the oracle's mp_conv (the wide tile with chunk-major K is what the headline 128x128 layers run;
@@ -209,7 +209,7 @@ def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
 
 @pytest.mark.parametrize("korder", [1, 2])
 @pytest.mark.parametrize("tile,cout,c1,scratch", [(0, 96, 160, True), (0, 384, 768, True), (1, 128, 256, False), (2, 256, 96, False), (3, 128, 64, False),
-                                                  (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False)])
+                                                  (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False), (7, 192, 384, False), (7, 96, 64, False)])
 def test_conv_glds_tail_segment(ctx, tile, cout, c1, scratch, korder):
     """A bf16x3 second source = 1-tap tail segment of the 3x3 K loop: conv_res1 + conv_skip of a decoder block as ONE GEMM,
         x = mp_sum(conv_skip(x_cat), conv_res1(y), t) = clip(ta * W_skip x_cat + tb * W_res1 * y)        training/models.py:184-186, 204-205

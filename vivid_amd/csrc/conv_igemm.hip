@@ -260,7 +260,8 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_QKV, "vh_conv: bad epilogue");
     VH_REQUIRE(a.stagger >= 0 && a.stagger <= 2, "vh_conv: stagger must be 0, 1 or 2");
     VH_REQUIRE(a.korder >= VH_KORDER_AUTO && a.korder <= VH_KORDER_CHUNK, "vh_conv: korder must be VH_KORDER_AUTO, _TAP or _CHUNK");
-    VH_REQUIRE(a.tile >= VH_TILE_AUTO && a.tile <= VH_TILE_256x64, "vh_conv: tile must be one of VH_TILE_*");
+    VH_REQUIRE((a.tile >= VH_TILE_AUTO && a.tile <= VH_TILE_256x64) || a.tile == VH_TILE_256x192, "vh_conv: tile must be one of VH_TILE_*");
+    VH_REQUIRE(a.tile != VH_TILE_256x192 || a.taps == 9, "vh_conv: VH_TILE_256x192 exists for 3x3 convolutions only");
     VH_REQUIRE(a.tile == VH_TILE_AUTO || a.kernel == VH_CONV_GLDS256, "vh_conv: a forced tile shape exists only for VH_CONV_GLDS256");
     if (a.epi == VH_EPI_QKV) {
         VH_REQUIRE(a.qkv && a.taps == 1 && a.kernel == VH_CONV_GLDS256 && !a.out && !a.out_s8, "vh_conv: QKV epilogue needs qkv args, a 1x1 GLDS convolution and no other output");

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce(const ConvK a, long lo
         else VH_LAUNCH(T, 4, 2, 2, 2, CH_);                    \
     } while (0)
 
-// cfg: 0 = 256x128 tile, 1 = 256x256, 2 = 512x128, 3 = 512x64, 5 = 256x64 (two workgroups per CU)
+// cfg: 0 = 256x128 tile, 1 = 256x256, 2 = 512x128, 3 = 512x64, 5 = 256x64 (two workgroups per CU), 7 = 256x192 (3x3 only)
 #if VH_CONV_TU != 9
 void vh_conv_x3_launch_1tap(const vhconv::ConvK& k, int cfg, unsigned grid, hipStream_t s) { VH_LAUNCH_CFG(1, false); }
 #else
@@ -644,12 +644,17 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         if ((a.tile == VH_TILE_512x64 || a.tile == VH_TILE_256x64) && a.cout > 64) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_512x64 / VH_TILE_256x64 need cout <= 64 (got %d)", a.cout);
         wide = a.tile == VH_TILE_256x256; tall = a.tile == VH_TILE_512x128; slim = a.tile == VH_TILE_512x64 || a.tile == VH_TILE_256x64;
     }
+    // 256x192 tiles (wave tile 64x96) for 3x3 convolutions whose Cout is a multiple of 192 but not of 128 (the 192-channel level of the
+    // super-resolution UNet): a 128-wide tile would run its second column of tiles half empty (256 / 192 = 1.33x the MFMA work)
+    const bool n192 = a.taps == 9 && (a.tile == VH_TILE_256x192 ||
+                      (a.tile == VH_TILE_AUTO && a.cout % 192 == 0 && a.cout % 128 != 0 && ((M + 255) / 256) * (a.cout / 192) >= 256));
+    if (n192) wide = tall = slim = false;
     // 256x64 with two workgroups per CU instead of 512x64 with one: +7..15 % on every Cout <= 64 layer measured (3x3 with 18-54 K-tiles, 1x1;
     // fp32 or S8 output; profiles/r03_ab_conv_slim2.txt) - one workgroup's prologue, epilogue and turnaround run under the other's K loop.
     // Knob "conv_slim2": -1 (default) always, 0 never (the 512x64 tile stays reachable for A/B and through vh_conv_args.tile).
     const int slim2_knob = vh_knob(VH_KNOB_CONV_SLIM2);
     const bool slim2 = slim && (a.tile == VH_TILE_256x64 || (a.tile == VH_TILE_AUTO && slim2_knob != 0));
-    const int BN = wide ? 256 : slim ? 64 : 128, BMt = (slim2 || (slim && a.src1)) ? 256 : (tall || slim) ? 512 : 256;
+    const int BN = n192 ? 192 : wide ? 256 : slim ? 64 : 128, BMt = (slim2 || (slim && a.src1)) ? 256 : (tall || slim) ? 512 : 256;
     const long long MT = (M + BMt - 1) / BMt, NT = (a.cout + BN - 1) / BN;
     if (MT * NT >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
     k.NT = (int)NT;
@@ -693,7 +698,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     const unsigned grid = (unsigned)(MT * NT * ksplit);
     const int taps = a.taps;
     const bool has_tail = a.src1 != nullptr;               // (validated by vh_conv: bf16x3, 3x3, no `up`)
-    const int cfg = (slim2 || (slim && has_tail)) ? 5 : slim ? 3 : tall ? 2 : wide ? 1 : 0;       // (a tail launch with Cout <= 64 always takes the 256x64 tile)
+    const int cfg = n192 ? 7 : (slim2 || (slim && has_tail)) ? 5 : slim ? 3 : tall ? 2 : wide ? 1 : 0;       // (a tail launch with Cout <= 64 always takes the 256x64 tile)
     if (has_tail && (cfg == 1 || cfg == 2) && a.cin_pad > BK) k.korder = 1;
     const int stagger_env = vh_knob(VH_KNOB_CONV_STAGGER);
     k.stagger = stagger_env >= 0 ? stagger_env : (a.stagger == 1 ? 1 : 0);       // default: off (see the kernel's note on `late`)
@@ -702,11 +707,13 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         if (taps == 9 && k.c1 > 0) {
             // tail instantiations: 256x128 and 256x64 in both K orders; 512x128 and 256x256 chunk-major only (the dispatcher forces that
             // order for them: tap-major they are 2 registers over the limit, and no launch the size rule makes would take them tap-major)
-            if (cfg == 2) VH_LAUNCH_TAIL(4, 2, 4, 2, true, 2);
+            if (cfg == 7) { if (chunk) VH_LAUNCH_TAIL(4, 2, 2, 3, true, 2); else VH_LAUNCH_TAIL(4, 2, 2, 3, false, 2); }
+            else if (cfg == 2) VH_LAUNCH_TAIL(4, 2, 4, 2, true, 2);
             else if (cfg == 1) VH_LAUNCH_TAIL(2, 4, 4, 2, true, 2);
             else if (cfg == 5) { if (chunk) VH_LAUNCH_TAIL(8, 1, 1, 2, true, 4); else VH_LAUNCH_TAIL(8, 1, 1, 2, false, 4); }
             else { if (chunk) VH_LAUNCH_TAIL(4, 2, 2, 2, true, 2); else VH_LAUNCH_TAIL(4, 2, 2, 2, false, 2); }
         }
+        else if (taps == 9 && cfg == 7) { if (chunk) VH_LAUNCH(9, 4, 2, 2, 3, true); else VH_LAUNCH(9, 4, 2, 2, 3, false); }
         else if (taps == 9) { if (chunk) VH_LAUNCH_CFG(9, true); else VH_LAUNCH_CFG(9, false); }
         else vh_conv_x3_launch_1tap(k, cfg, grid, s);
         if (k.ksplit > 1) {
