@@ -647,7 +647,10 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // 256x192 tiles (wave tile 64x96) for 3x3 convolutions whose Cout is a multiple of 192 but not of 128 (the 192-channel level of the
     // super-resolution UNet): a 128-wide tile would run its second column of tiles half empty (256 / 192 = 1.33x the MFMA work)
     const bool n192 = a.taps == 9 && (a.tile == VH_TILE_256x192 ||
-                      (a.tile == VH_TILE_AUTO && a.cout % 192 == 0 && a.cout % 128 != 0 && ((M + 255) / 256) * (a.cout / 192) >= 256));
+                      (a.tile == VH_TILE_AUTO && a.cout % 192 == 0 && (a.cout % 128 != 0 || (!wide && !tall && !slim)) &&
+                       ((M + 255) / 256) * (a.cout / 192) >= 256));
+    // (Cout = 384 at 65536 pixels - the guidance net's 64x64 level in C2: too few pixels for 512-row tiles, and 256 x 2 tiles of 256x192 are two
+    //  full rounds of the chip where 256 x 3 tiles of 256x128 are three: +10 %, profiles/r03_ab_conv_256x192_tile.txt)
     if (n192) wide = tall = slim = false;
     // 256x64 with two workgroups per CU instead of 512x64 with one: +7..15 % on every Cout <= 64 layer measured (3x3 with 18-54 K-tiles, 1x1;
     // fp32 or S8 output; profiles/r03_ab_conv_slim2.txt) - one workgroup's prologue, epilogue and turnaround run under the other's K loop.
