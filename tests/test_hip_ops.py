@@ -129,6 +129,9 @@ def _rand_conv_shapes():
     out.append((1, 16, 16, 384, 384, 9, 2, 0))
     out.append((2, 8, 8, 512, 512, 1, 2, 0))
     out.append((1, 16, 16, 768, 384, 1, 0, 0))
+    out.append((3, 16, 16, 192, 192, 9, 1, 1))         # 256x192 tiles (Cout % 192 == 0) with split-K, with `up`, ragged M
+    out.append((2, 32, 32, 96, 192, 9, 0, 0))
+    out.append((5, 12, 20, 160, 576, 9, 2, 0))
     return out
 
 

@@ -635,7 +635,11 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // 256x256 tiles when Cout allows it and the grid still gives every CU (256) a workgroup; otherwise 256x128
     bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
     // 512x128 tiles (same 128x64 wave tile as the wide config) when only the narrow N fits and M is large
-    bool tall = !wide && ((M + 511) / 512) * ((a.cout + 127) / 128) >= 512;
+    // (round 3: also between 256 and 511 such tiles when that is no more rounds of the chip, weighted by the tile's work (2 x a 256x128 tile at
+    //  ~0.88 of its time per flop), than the 256x128 tiles would take - 256 tall tiles are ONE round where 512 narrow ones are two: +12..14 % at
+    //  32x64x64 pixels, Cout = 128, profiles/r03_ab_conv_tile_choice_small_launches.txt)
+    const long long Tt = ((M + 511) / 512) * ((a.cout + 127) / 128), Tn = ((M + 255) / 256) * ((a.cout + 127) / 128);
+    bool tall = !wide && (Tt >= 512 || (Tt >= 256 && (double)((Tt + 255) / 256) * 1.76 <= (double)((Tn + 255) / 256)));
     // 512x64 tiles (8 waves of 64x64) for Cout <= 64 at large M - the full-resolution layers of the super-resolution net,
     // where a 128-wide tile would spend half of its MFMAs and B traffic on zero columns
     bool slim = a.cout <= 64 && (M + 511) / 512 >= 512;
@@ -647,10 +651,12 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     // 256x192 tiles (wave tile 64x96) for 3x3 convolutions whose Cout is a multiple of 192 but not of 128 (the 192-channel level of the
     // super-resolution UNet): a 128-wide tile would run its second column of tiles half empty (256 / 192 = 1.33x the MFMA work)
     const bool n192 = a.taps == 9 && (a.tile == VH_TILE_256x192 ||
-                      (a.tile == VH_TILE_AUTO && a.cout % 192 == 0 && (a.cout % 128 != 0 || (!wide && !tall && !slim)) &&
-                       ((M + 255) / 256) * (a.cout / 192) >= 256));
-    // (Cout = 384 at 65536 pixels - the guidance net's 64x64 level in C2: too few pixels for 512-row tiles, and 256 x 2 tiles of 256x192 are two
-    //  full rounds of the chip where 256 x 3 tiles of 256x128 are three: +10 %, profiles/r03_ab_conv_256x192_tile.txt)
+                      (a.tile == VH_TILE_AUTO && a.cout % 192 == 0 && !slim && (a.cout % 128 != 0 || (!wide && !tall)) &&
+                       ((M + 255) / 256) * (a.cout / 192) >= 64));      // (below a quarter of the chip the launch is latency-bound: more, smaller tiles)
+    // (Cout = 384 wherever the pixels are too few for 512-row tiles: at 65536 pixels - the guidance net's 64x64 level in C2 - 256 x 2 tiles of
+    //  256x192 are two full rounds of the chip where 256 x 3 tiles of 256x128 are three, +10 %; at 8192-16384 pixels - the 16x16 level of the
+    //  reference's base@64 preset at batch 32 - the bigger wave tile alone is worth +6..25 %, growing with K; profiles/r03_ab_conv_256x192_tile.txt,
+    //  r03_ab_conv_tile_choice_small_launches.txt)
     if (n192) wide = tall = slim = false;
     // 256x64 with two workgroups per CU instead of 512x64 with one: +7..15 % on every Cout <= 64 layer measured (3x3 with 18-54 K-tiles, 1x1;
     // fp32 or S8 output; profiles/r03_ab_conv_slim2.txt) - one workgroup's prologue, epilogue and turnaround run under the other's K loop.
