@@ -642,7 +642,9 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     bool tall = !wide && (Tt >= 512 || (Tt >= 256 && (double)((Tt + 255) / 256) * 1.76 <= (double)((Tn + 255) / 256)));
     // 512x64 tiles (8 waves of 64x64) for Cout <= 64 at large M - the full-resolution layers of the super-resolution net,
     // where a 128-wide tile would spend half of its MFMAs and B traffic on zero columns
-    bool slim = a.cout <= 64 && (M + 511) / 512 >= 512;
+    // (round 3, late: at ANY M - below 512 such tiles the 128-wide tiles this used to fall back to still spend half their MFMAs on zero columns:
+    //  256x64 is +7..45 % on 1-4 rows of 256x256 and on the 3-channel output convolutions, profiles/r03_ab_conv_tile_choice_small_launches.txt)
+    bool slim = a.cout <= 64;
     if (a.tile != VH_TILE_AUTO) {                          // caller's choice (tests sweep every shape on small problems)
         if (a.tile == VH_TILE_256x256 && a.cout % 256) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_256x256 needs cout %% 256 == 0 (got %d)", a.cout);
         if ((a.tile == VH_TILE_512x64 || a.tile == VH_TILE_256x64) && a.cout > 64) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_512x64 / VH_TILE_256x64 need cout <= 64 (got %d)", a.cout);
