@@ -633,7 +633,10 @@ int vh_diag_conv3() { return VH_DIAG_FLAG; }
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
     // 256x256 tiles when Cout allows it and the grid still gives every CU (256) a workgroup; otherwise 256x128
-    bool wide = a.cout % 256 == 0 && ((M + 255) / 256) * (a.cout / 256) >= 256;
+    // (round 3, late: from 128 workgroups on when the K loop is long - 216+ K-tiles: half a round of the bigger wave tile then beats a full
+    //  round of 256x128 tiles by 3..11 %, growing with K; at 108-144 K-tiles it loses 1..8 %; profiles/r03_ab_conv_tile_choice_small_launches.txt)
+    const long long Tw = ((M + 255) / 256) * (a.cout / 256);
+    bool wide = a.cout % 256 == 0 && (Tw >= 256 || (Tw >= 128 && a.k_pad / BK >= 216));
     // 512x128 tiles (same 128x64 wave tile as the wide config) when only the narrow N fits and M is large
     // (round 3: also between 256 and 511 such tiles when that is no more rounds of the chip, weighted by the tile's work (2 x a 256x128 tile at
     //  ~0.88 of its time per flop), than the 256x128 tiles would take - 256 tall tiles are ONE round where 512 narrow ones are two: +12..14 % at
