@@ -128,7 +128,7 @@ def main():
                            cvec=cvec.data_ptr() if cvec is not None else None, cvec_ld=cout if cvec is not None else 0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
                            korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0),
                            qkv=ct.addressof(qkv) if qkv is not None else None)
-            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, qkv, (Q, K, V) if epi == 3 else None, o8 if s8mode == 1 else out)))
+            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, qkv, (Q, K, V) if epi == 3 else None, o8, out, o8 if s8mode == 1 else out)))   # (every buffer the launch writes stays referenced)
 
     def launch(r, k):
         name, ctx, op, a, knobs, _ = r
