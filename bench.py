@@ -119,6 +119,36 @@ def build_nets(kind, R, precision, dev, guided):
     return net, gnet
 
 
+def host_core_allotment():
+    """Cores THIS job may use: the scheduler affinity mask, tightened by the cgroup CPU quota when there is one (cgroup v2 `cpu.max`,
+    v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  torch's default thread count is the machine's core count (128 on the GPU boxes), not
+    the job's share of it: running the oracle on that many threads oversubscribes the allotment and mis-states `cores`."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(cores=cores, affinity=aff, cgroup_quota=quota, cpu_model=model, os_cpu_count=os.cpu_count())
+
+
 def oracle_guided_eval(R):
     """The CPU oracle (a restatement of the reference's PyTorch-CPU path; kind="port") on a bounded sample: ONE guided evaluation at
     batch 1 of the headline networks, run twice - an untimed warm-up (thread pools, allocator, first-touch of 1 GB of weights), then
@@ -127,6 +157,9 @@ def oracle_guided_eval(R):
     from oracle import vivid_ref as Rf
     import vivid_amd
     torch.set_grad_enabled(False)
+    host = host_core_allotment()
+    threads_default = torch.get_num_threads()
+    torch.set_num_threads(host["cores"])          # the job's allotment, not the machine's core count ("core count stated")
     cfg, ucfg = vivid_amd.vivid_base(R), vivid_amd.vivid_uncond(R)
     d, ud = cfg.to_dict(), ucfg.to_dict()
     d.pop("use_fp16"); ud.pop("use_fp16")
@@ -142,7 +175,9 @@ def oracle_guided_eval(R):
         ref = gnet(src, x, t)
         guided = ref.lerp(D, 1.5)
         times.append(time.perf_counter() - t0)
-    return dict(seconds_b1=times[1], seconds_b1_cold=times[0], cores=torch.get_num_threads(), D=D, guided=guided,
+    used = torch.get_num_threads()
+    torch.set_num_threads(threads_default)
+    return dict(seconds_b1=times[1], seconds_b1_cold=times[0], cores=used, host=host, torch_threads_default=threads_default, D=D, guided=guided,
                 inputs=(src, x, t, geo))
 
 
@@ -480,6 +515,9 @@ def main():
                                      and out["parity"][f"batch{B}_vs_batch1"] < 2e-5)
         del srcB, noiseB, geoB, xB, DB, GB
         out["cpu_baseline"] = {"value": 1.0 / (B * cb["seconds_b1"]), "unit": out["unit"], "cores": cb["cores"], "kind": "port",
+                               "cpu_model": cb["host"]["cpu_model"], "sched_affinity_cores": cb["host"]["affinity"],
+                               "cgroup_cpu_quota": cb["host"]["cgroup_quota"], "os_cpu_count": cb["host"]["os_cpu_count"],
+                               "torch_threads_default": cb["torch_threads_default"],
                                "sample": f"one guided evaluation (net + uncond gnet) of the same {R}x{R} networks at batch 1 on the CPU oracle "
                                          f"took {cb['seconds_b1']:.2f} s after one untimed warm-up call ({cb['seconds_b1_cold']:.2f} s cold); "
                                          f"a batch-{B} step is {B} of them (cost linear in batch)"}

@@ -25,26 +25,67 @@ def test_library_exports_every_declared_symbol():
     assert L.vh_abi_version() == _lib.ABI_VERSION
 
 
-def test_struct_mirrors_match_header_field_counts():
-    h = _header()
-    pairs = {"vh_prep_weight_args": _lib.PrepWeightArgs, "vh_conv_args": _lib.ConvArgs, "vh_pixnorm_args": _lib.PixnormArgs,
-             "vh_qkv_split_args": _lib.QkvSplitArgs, "vh_split_args": _lib.SplitArgs, "vh_attention_args": _lib.AttentionArgs, "vh_embed_args": _lib.EmbedArgs,
-             "vh_linear_args": _lib.LinearArgs, "vh_segment": _lib.Segment, "vh_assemble_args": _lib.AssembleArgs,
-             "vh_precond_out_args": _lib.PrecondOutArgs, "vh_warp_args": _lib.WarpArgs,
-             "vh_sampler_step_args": _lib.SamplerStepArgs, "vh_qkv_epilogue": _lib.QkvEpilogue, "vh_codec_args": _lib.CodecArgs, "vh_add_depth_args": _lib.AddDepthArgs, "vh_resize_args": _lib.ResizeArgs,
-             "vh_nonzero_args": _lib.NonzeroArgs, "vh_resample_args": _lib.ResampleArgs, "vh_moments_args": _lib.MomentsArgs,
-             "vh_psnr_args": _lib.PsnrArgs, "vh_net_config": _lib.NetConfigC}
-    for cname, st in pairs.items():
-        m = re.search(r"typedef struct \{([^{}]*)\}\s*" + cname + r"\s*;", h, flags=re.S)
-        assert m, cname
+STRUCT_MIRRORS = {"vh_prep_weight_args": "PrepWeightArgs", "vh_conv_args": "ConvArgs", "vh_pixnorm_args": "PixnormArgs",
+                  "vh_qkv_split_args": "QkvSplitArgs", "vh_split_args": "SplitArgs", "vh_attention_args": "AttentionArgs",
+                  "vh_embed_args": "EmbedArgs", "vh_linear_args": "LinearArgs", "vh_segment": "Segment", "vh_assemble_args": "AssembleArgs",
+                  "vh_precond_out_args": "PrecondOutArgs", "vh_warp_args": "WarpArgs", "vh_sampler_step_args": "SamplerStepArgs",
+                  "vh_qkv_epilogue": "QkvEpilogue", "vh_codec_args": "CodecArgs", "vh_add_depth_args": "AddDepthArgs",
+                  "vh_resize_args": "ResizeArgs", "vh_nonzero_args": "NonzeroArgs", "vh_resample_args": "ResampleArgs",
+                  "vh_moments_args": "MomentsArgs", "vh_psnr_args": "PsnrArgs", "vh_net_config": "NetConfigC"}
+
+
+def _header_structs():
+    """{struct name: [field names in declaration order]} parsed from the header's `typedef struct { ... } name;` blocks."""
+    out = {}
+    for m in re.finditer(r"typedef struct \{([^{}]*)\}\s*(\w+)\s*;", _header(), flags=re.S):
         body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
-        n = 0
+        names = []
         for decl in body.split(";"):
             decl = decl.strip()
             if not decl:
                 continue
-            n += decl.count(",") + 1
-        assert n == len(st._fields_), (cname, n, len(st._fields_))
+            for d in decl.split(","):
+                d = re.sub(r"\[[^\]]*\]", "", d).strip()          # drop array extents
+                names.append(re.findall(r"(\w+)\s*$", d)[0])       # the declarator's identifier is its last word
+        out[m.group(2)] = names
+    return out
+
+
+def test_struct_mirrors_match_header_layout(tmp_path):
+    """Layout, not field counts: a C program compiled against include/vivid_hip.h prints sizeof / offsetof of every field of every
+    argument struct; the ctypes mirrors in _lib.py must agree field by field (a size_t <-> int swap or two reordered fields of the same
+    count would pass a count check and corrupt every call)."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    structs = _header_structs()
+    assert set(structs) == set(STRUCT_MIRRORS), (sorted(set(structs) ^ set(STRUCT_MIRRORS)))
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "vivid_hip.h"', "int main(void) {"]
+    for sname, fields in structs.items():
+        lines.append(f'  printf("S {sname} %zu\\n", sizeof({sname}));')
+        for f in fields:
+            lines.append(f'  printf("F {sname} {f} %zu %zu\\n", offsetof({sname}, {f}), sizeof((({sname}*)0)->{f}));')
+    lines += ["  return 0;", "}"]
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text("\n".join(lines))
+    subprocess.check_call([cc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    rows = subprocess.check_output([str(exe)], text=True).split("\n")
+    sizes, fields = {}, {}
+    for r in rows:
+        t = r.split()
+        if t and t[0] == "S":
+            sizes[t[1]] = int(t[2])
+        elif t and t[0] == "F":
+            fields.setdefault(t[1], []).append((t[2], int(t[3]), int(t[4])))
+    for sname, pyname in STRUCT_MIRRORS.items():
+        st = getattr(_lib, pyname)
+        assert C.sizeof(st) == sizes[sname], (sname, C.sizeof(st), sizes[sname])
+        assert len(st._fields_) == len(fields[sname]), (sname, len(st._fields_), len(fields[sname]))
+        for (pyfield, ctype), (cfield, off, size) in zip(st._fields_, fields[sname]):
+            d = getattr(st, pyfield)
+            assert (d.offset, d.size) == (off, size), f"{sname}.{cfield} (ctypes {pyname}.{pyfield}): ctypes offset/size {(d.offset, d.size)}, C {(off, size)}"
 
 
 def test_argument_validation_without_gpu():

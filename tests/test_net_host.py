@@ -73,6 +73,11 @@ def test_stacked_generator_streams_depend_on_the_seed_only():
     assert torch.equal(ref, x)
     with pytest.raises(ValueError):
         a.randn([2, 3, 8, 8])
+    # randint (generate_images.py:132-134): the same per-seed streams, the reference's keyword-only `size`
+    c = vivid_amd.StackedRandomGenerator("cpu", [5, 6]).randint(10, size=[2, 4])
+    want = torch.stack([torch.randint(10, size=[4], generator=torch.Generator().manual_seed(s)) for s in (5, 6)])
+    assert torch.equal(c, want)
+    assert torch.equal(vivid_amd.StackedRandomGenerator("cpu", [6]).randint(10, size=[1, 4])[0], c[1])
 
 
 def test_library_is_a_product_build():

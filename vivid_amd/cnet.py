@@ -72,6 +72,8 @@ class CNet:
             L.check(self._L.vh_net_bind_param(self.handle, key.encode(), C.c_void_p(t.data_ptr())), "vh_net_bind_param")
         nbytes = self._L.vh_net_prepared_bytes(self.handle)
         self._prepared = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=device)
+        # the `.to(device)` copies above ran on torch's current stream: prepare on that stream, not on the one the context was created with
+        self.ctx.set_stream(torch.cuda.current_stream(torch.device(device)).cuda_stream)
         L.check(self._L.vh_net_prepare(self.handle, C.c_void_p(self._prepared.data_ptr()), nbytes), "vh_net_prepare")
         self._ws = {}
 

@@ -158,6 +158,7 @@ struct Program {
     int B = 0, mode = 0;
     vh_plan* plan = nullptr;
     float* base = nullptr;
+    float* feat_base = nullptr;       // VH_NET_BOUND: workspace base of the VH_NET_FEATURES program whose buffers this plan reads in place
     Buf sigma, geometry, src, x, cond, D;
     std::vector<FeatBuf> feats;       // VH_NET_FEATURES: the encoder's feature list, (fp32, S8) pairs inside this program's workspace
     long long peak_floats = 0;
@@ -743,6 +744,7 @@ static int net_build(vh_net* n, int mode, int slot, int B, float* workspace, siz
     rc = vh_plan_end(n->ctx, &rec.plan);
     if (rc != VH_OK) return rc;
     rec.base = workspace; rec.peak_floats = real.peak;
+    if (mode == VH_NET_BOUND) rec.feat_base = n->programs.at(std::make_tuple((int)VH_NET_FEATURES, slot, B))->base;
     *pr = rec;
     *out = pr.release();
     return VH_OK;
@@ -767,6 +769,13 @@ extern "C" int vh_net_record_mode(vh_net* n, int mode, int slot, int batch, void
     auto it = n->programs.find(key);
     if (it != n->programs.end() && it->second->plan) (void)vh_plan_destroy(it->second->plan);
     n->programs[key].reset(p);
+    if (mode == VH_NET_FEATURES) {
+        // a VH_NET_BOUND program holds ABSOLUTE pointers into the workspace of the VH_NET_FEATURES program it was recorded against: a re-recorded
+        // (possibly moved) FEATURES program leaves it reading the old addresses - drop it, so that vh_net_run_bound reports "no program
+        // recorded" until the host records the BOUND program again
+        auto bt = n->programs.find(std::make_tuple((int)VH_NET_BOUND, slot, batch));
+        if (bt != n->programs.end()) { if (bt->second && bt->second->plan) (void)vh_plan_destroy(bt->second->plan); n->programs.erase(bt); }
+    }
     return VH_OK;
 }
 extern "C" int vh_net_record(vh_net* n, int batch, void* workspace, size_t bytes) { return vh_net_record_mode(n, VH_NET_FULL, 0, batch, workspace, bytes); }
@@ -778,6 +787,13 @@ static int net_run(vh_net* n, int mode, int slot, int batch, const float* src, c
     auto it = n->programs.find(std::make_tuple(mode, slot, batch));
     VH_REQUIRE(it != n->programs.end() && it->second->plan, "vh_net: no program recorded for mode %d, slot %d, batch %d (vh_net_record / vh_net_record_mode)", mode, slot, batch);
     Program& p = *it->second;
+    if (!n->prepared) return vh_fail(VH_ESTATE, "vh_net: a parameter was re-bound after vh_net_prepare: call vh_net_prepare (and record) again");
+    if (mode == VH_NET_BOUND) {
+        // the features this program reads in place must still be where they were when it was recorded
+        auto ft = n->programs.find(std::make_tuple((int)VH_NET_FEATURES, slot, batch));
+        if (ft == n->programs.end() || ft->second->base != p.feat_base)
+            return vh_fail(VH_ESTATE, "vh_net_run_bound: the VH_NET_FEATURES program of slot %d, batch %d was re-recorded: record the VH_NET_BOUND program again", slot, batch);
+    }
     hipStream_t s = n->ctx->stream;
     auto put = [&](const Buf& b, const float* from) -> int {
         if (!b.ok()) return VH_OK;

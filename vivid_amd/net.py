@@ -146,6 +146,7 @@ class NVPrecond(torch.nn.Module):
         self._prepared_fp = None
         self._tensors = None            # flat list of parameters and buffers (rebuilt after _apply / load_state_dict)
         self._weights_epoch = 0
+        self._enc_event = None          # end of the last encode_features launch (it may still be running on another stream)
 
     @classmethod
     def from_config(cls, cfg: NetConfig, dual_source: bool = True, precision=None) -> "NVPrecond":
@@ -223,11 +224,23 @@ class NVPrecond(torch.nn.Module):
             if geometry is None:
                 raise TypeError("geometry is required (the reference multiplies None by an int here, :631)")
             prog = eng.program("features", B, bool(cfg.super_res), False, slot=slot)
+            self._order_after_encoder(dev)
             self._put(prog, "sigma", sigma.reshape(-1), (rows,))
             self._put(prog, "geometry", geometry.reshape(rows, -1), (rows, cfg.source_label_dim))
             self._put(prog, "src", src, (rows, src_c, R, R))
             prog.plan.run()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            self._enc_event = ev
             return FeatureHandle(self, slot, B, self._prepared_fp)
+
+    def _order_after_encoder(self, dev):
+        """Programs that run the ENCODER ('full', 'features') share its split-K scratch (Engine.scratch_enc) and the engine's one
+        context: a whole evaluation issued on this stream while a look-ahead encode_features is still running on another one would
+        interleave partial sums with it.  Make this stream wait for the last encoder launch first (free when it already finished or
+        ran on this stream); 'bound' / 'inject' / 'uncond' programs touch only the UNet's scratch and need no ordering."""
+        if self._enc_event is not None:
+            torch.cuda.current_stream(dev).wait_event(self._enc_event)
 
     @staticmethod
     def _put(prog, name, t, shape):
@@ -293,6 +306,8 @@ class NVPrecond(torch.nn.Module):
             if mode is None:     # uncond net asked for features: the zero list of :727-736
                 return [torch.zeros(rows, c, r, r, device=dev) for (c, r) in eng._feature_shapes()]
             prog = eng.program(mode, B, has_cond, bool(return_logvar), slot=handle.slot if handle is not None else 0)
+            if mode in ("full", "features"):
+                self._order_after_encoder(dev)
 
             def put(name, t, shape):
                 self._put(prog, name, t, shape)

@@ -9,8 +9,8 @@ feature reuse for ``no_time_enc`` nets (:52-53).  The per-step arithmetic runs i
 one HIP kernel (``vh_sampler_step``); the denoiser calls go to whatever ``net`` /
 ``gnet`` are (normally :class:`vivid_amd.NVPrecond`).
 
-``StackedRandomGenerator`` keeps the contract of ``generate_images.py:120-134`` (per-seed streams); its ``randint`` has no
-caller on this path and is not provided.
+``StackedRandomGenerator`` keeps the contract of ``generate_images.py:120-134`` (per-seed streams: ``randn``, ``randn_like``,
+``randint``).
 """
 from __future__ import annotations
 
@@ -136,9 +136,14 @@ class _FeaturePipeline:
         return self.cur[1]
 
 
-def _pipeline_capable(net, src) -> bool:
+def _pipeline_capable(net, src, gnet=None, guidance=1) -> bool:
     env = os.environ.get("VIVID_FEATURE_PIPELINE")
     if env == "0":
+        return False
+    if gnet is net and guidance != 1:
+        # the guidance call `gnet(src, x, t)` would be a whole ('full') evaluation of the SAME engine on the main stream while that
+        # engine's look-ahead encoder runs on the side stream.  NVPrecond orders the two (its whole evaluations wait for an outstanding
+        # look-ahead), so results would stay right, but nothing is gained: keep the plain call pattern.
         return False
     return hasattr(net, "encode_features") and not getattr(net, "uncond", None) and not getattr(net, "no_time_enc", None)
 
@@ -168,7 +173,7 @@ def edm_sampler(
 
         # The noise level of every denoiser call of this run, in call order (Euler call at t_hat, Heun probe at t_next; :78-84, :104)
         pipe, calls = None, [0]
-        if features is None and _pipeline_capable(net, src):
+        if features is None and _pipeline_capable(net, src, gnet, guidance):
             levels = []
             for i, (t_cur, t_next) in enumerate(zip(t_steps[:-1], t_steps[1:])):
                 churn = S_churn > 0 and S_min <= t_cur <= S_max
@@ -236,3 +241,7 @@ class StackedRandomGenerator:
 
     def randn_like(self, input):
         return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
+
+    def randint(self, *args, size, **kwargs):
+        """Per-seed integer draws (generate_images.py:132-134; EDM2-style scripts draw class labels with it)."""
+        return self._stacked(lambda shape, g: torch.randint(*args, size=shape, generator=g, **kwargs), size)
