@@ -57,7 +57,9 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * "attn_nomax": 1 (default) bounded-logit attention keeps no running maximum, 0 keeps it;
  * "conv_slim2": -1 (default) Cout <= 64 layers at large M take the 256x64 tile (two workgroups per CU), 0 the 512x64 one;
  * "conv_korder_mb": input size in MB above which 3x3 convolutions take the chunk-major K order (default: see conv_x3.hip);
- * "conv_ksplit": > 0 forces that many K slices where split-K is possible (default 0: the dispatcher's rule).
+ * "conv_ksplit": > 0 forces that many K slices where split-K is possible (default 0: the dispatcher's rule);
+ * "conv_patch": -1 (default) eligible 3x3 Cout == 64 layers take the patch-resident kernel by the size rule, 0 never, 1 whenever eligible;
+ * "conv_patch_delay": start delay, in units of 2048 shader cycles, of every CU's second workgroup in the first round of a patch-kernel launch.
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);
 
@@ -184,10 +186,15 @@ typedef struct {
                                               (pixels x output channels): VH_TILE_256x128, VH_TILE_256x256 (needs cout % 256 == 0),
                                               VH_TILE_512x128, VH_TILE_512x64 and VH_TILE_256x64 (need cout <= 64; the latter runs two
                                               workgroups per CU), VH_TILE_256x192 (3x3 only).  A forced shape disables split-K unless
-                                              the grid is small; every shape computes the same sums in the same order. */
+                                              the grid is small; every shape computes the same sums in the same order.
+                                              VH_TILE_PATCH16: the patch-resident kernel (conv_patch.hip) - 3x3, no `up`, cout == 64, no res_up: one
+                                              workgroup per 16x16-pixel output tile of one image, its (16+2)^2-pixel input patch staged once per
+                                              32-channel chunk and read in place by the nine taps; chunk-major K order (sums agree with the other
+                                              tiles to fp32 rounding). */
 } vh_conv_args;
 enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
-enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5, VH_TILE_256x192 = 7 };
+enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5, VH_TILE_256x192 = 7,
+       VH_TILE_PATCH16 = 8 };
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
 
 /* ---- K6 (+K9): pixel norm with optional 2x2 mean pooling ------------------

@@ -173,7 +173,7 @@ def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("korder", [1, 2])                  # VH_KORDER_TAP, VH_KORDER_CHUNK
-@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32), (7, 192), (7, 96), (7, 384)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU), 256x192 (+ ragged N, two N-tiles)
+@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32), (7, 192), (7, 96), (7, 384), (8, 64)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU), 256x192 (+ ragged N, two N-tiles), the patch-resident kernel (16x16-pixel tiles hanging over both image edges)
 def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
     """Every workgroup tile of conv_x3_glds with both K orders and every epilogue, forced through vh_conv_args.tile / .korder on a
     small ragged problem, against the oracle's mp_conv (the wide tile with chunk-major K is what the headline 128x128 layers run;
@@ -210,9 +210,45 @@ def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
         assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5
 
 
+@pytest.mark.parametrize("epi", [0, 2])
+@pytest.mark.parametrize("rows,h,w,cin", [(3, 32, 48, 64), (1, 40, 17, 64), (2, 16, 16, 32), (1, 128, 96, 256), (2, 256, 256, 64)])
+def test_conv_patch_kernel_shapes(ctx, rows, h, w, cin, epi):
+    """conv_x3_patch (VH_TILE_PATCH16) beyond the sweep's 96-channel case: 64 channels = the two-chunk instantiation that requests the next
+    chunk's patch ahead (registers + landing pad), one chunk (no boundary at all), eight chunks; whole tiles, tiles hanging over the right /
+    bottom edge by 15 of 16 pixels, and the size rule's own choice (tile = AUTO on a problem with >= 512 tiles) - against the oracle's mp_conv."""
+    from vivid_amd import _lib as L
+    cout = 64
+    g = torch.Generator().manual_seed(rows * 1000 + h + w + cin + epi)
+    x = torch.randn(rows, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g)
+    y = R.mp_conv(x, wgt, gain=1.0)
+    res = torch.randn(rows, cout, h, w, generator=g)
+    ta, tb, clip = 0.7, 0.3, 2.5
+    ref = (res * ta + y * tb).clip(-clip, clip) if epi == 2 else y
+    M = rows * h * w
+    xd = _nhwc(x).cuda()
+    xs8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+    rd = _nhwc(res).cuda()
+    for tile in (8, 0):
+        out = torch.full((M, cout), float("nan"), device="cuda")
+        o8 = torch.empty(M * cout, device="cuda")
+        ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                      taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                      scratch=None, scratch_floats=0, cout=cout, out=out.data_ptr(), out_s8=o8.data_ptr(), out_s8_c=cout,
+                                      prec=1, kernel=1, epi=epi, cvec=None, cvec_ld=0, res=rd.data_ptr() if epi == 2 else None, res_up=0,
+                                      ta=ta, tb=tb, clip=clip if epi == 2 else 0, korder=0, tile=tile))
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5, tile
+        assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5, tile
+
+
 @pytest.mark.parametrize("korder", [1, 2])
 @pytest.mark.parametrize("tile,cout,c1,scratch", [(0, 96, 160, True), (0, 384, 768, True), (1, 128, 256, False), (2, 256, 96, False), (3, 128, 64, False),
-                                                  (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False), (7, 192, 384, False), (7, 96, 64, False)])
+                                                  (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False), (7, 192, 384, False), (7, 96, 64, False),
+                                                  (8, 64, 128, False), (8, 64, 32, False)])
 def test_conv_glds_tail_segment(ctx, tile, cout, c1, scratch, korder):
     """A bf16x3 second source = 1-tap tail segment of the 3x3 K loop: conv_res1 + conv_skip of a decoder block as ONE GEMM,
         x = mp_sum(conv_skip(x_cat), conv_res1(y), t) = clip(ta * W_skip x_cat + tb * W_res1 * y)        training/models.py:184-186, 204-205

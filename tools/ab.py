@@ -4,8 +4,9 @@
   python tools/ab.py attn  B HEADS S KL [D]            -- vh_attention_x3 as the engine calls it (bounded logits)
   python tools/ab.py pixnorm ROWS H W C                -- vh_pixnorm (scale + S8 of silu(normalised x)); "TF/s" column = GB/s
   python tools/ab.py split ROWS H W C0 C1 RAW          -- vh_split (concat + silu -> S8; RAW 1: also the raw S8 form); "TF/s" column = GB/s
-  python tools/ab.py conv  ROWS H W CIN COUT [TAPS] [EPI]  -- vh_conv, glds kernel (EPI 0 store, 1 cvec + silu, 2 residual mp_sum, 3 the q/k/v
-                                                           epilogue of attn_qkv: COUT = 3 * heads * 64, self keys only)
+  python tools/ab.py conv  ROWS H W CIN COUT [TAPS] [EPI] [C1]  -- vh_conv, glds kernel (EPI 0 store, 1 cvec + silu, 2 residual mp_sum, 3 the q/k/v
+                                                           epilogue of attn_qkv: COUT = 3 * heads * 64, self keys only; C1 > 0: a second S8 source
+                                                           of C1 channels as the 1-tap tail segment - conv_res1 + conv_skip as one GEMM)
 Variants come from VARIANTS="name=lib[:knob=val[,knob=val]];..." where lib is a suffix of vivid_amd/libvivid_hip[_<suffix>].so
 ("" = the product build), e.g.  VARIANTS="base=;dyn=attn_dyn;noxcd=:attn_xcd=0".
 Prints median and min ms per launch over ROUNDS (default 7) interleaved rounds of N (default 10) launches."""
@@ -21,7 +22,7 @@ import torch  # noqa: E402
 from vivid_amd import _lib as L  # noqa: E402
 
 
-KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0}
+KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0, "conv_patch": -1, "conv_patch_delay": 0}
 
 
 def load(suffix):
@@ -97,12 +98,15 @@ def main():
         rows, h, w, cin, cout = args[:5]
         taps = args[5] if len(args) > 5 else 9
         epi = args[6] if len(args) > 6 else 0
+        c1 = args[7] if len(args) > 7 else 0
         x = torch.randn(rows, h, w, cin, generator=g).cuda()
         wgt = torch.randn(cout, cin, *([3, 3] if taps == 9 else [1, 1]), generator=g).cuda()
         zeros = torch.zeros(16384, device="cuda")
         scr = torch.empty(16 << 20, device="cuda")
-        k_pad, M = taps * cin, rows * h * w
-        flops = 2.0 * M * cout * cin * taps
+        k_pad, M = taps * cin + c1, rows * h * w
+        flops = 2.0 * M * cout * (cin * taps + c1)
+        x1 = torch.randn(rows, h, w, c1, generator=g).cuda() if c1 else None
+        wgt1 = torch.randn(cout, c1, 1, 1, generator=g).cuda() if c1 else None
         res = torch.randn(M, cout, generator=g).cuda() if epi == 2 else None
         cvec = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda() if epi == 1 else None
         heads, S = cout // 192, h * w
@@ -111,8 +115,14 @@ def main():
             s8 = torch.empty(M * cin, device="cuda")
             ctx.call("vh_split", L.SplitArgs(src0=x.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin, out=s8.data_ptr(), out_raw=None))
             wt = torch.zeros(k_pad // 4 * cout * 4, device="cuda")
-            ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin, k_pad=k_pad, gain_ptr=None,
-                                                        gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2))
+            ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=taps, cin_pad=cin, k_pad=taps * cin, gain_ptr=None,
+                                                        gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2, k_off=0, k_stride=k_pad if c1 else 0))
+            s81 = None
+            if c1:
+                s81 = torch.empty(M * c1, device="cuda")
+                ctx.call("vh_split", L.SplitArgs(src0=x1.data_ptr(), src1=None, c0=c1, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=c1, out=s81.data_ptr(), out_raw=None))
+                ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt1.data_ptr(), cout=cout, cin=c1, taps=1, cin_pad=c1, k_pad=c1, gain_ptr=None,
+                                                            gain_value=1.0, wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2, k_off=taps * cin, k_stride=k_pad))
             out = torch.empty(M, cout, device="cuda")
             qkv = None
             if epi == 3:
@@ -121,14 +131,14 @@ def main():
                 out = torch.cat([Q, K, V])                  # (a copy: the comparison below is then trivially 0; timing only)
             s8mode = knobs.pop("s8", 0)                     # 0: fp32 output, 1: S8 only, 2: both
             o8 = torch.empty(M * cout, device="cuda") if s8mode else None
-            a = L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=taps, pro=0,
+            a = L.ConvArgs(src0=s8.data_ptr(), src1=s81.data_ptr() if c1 else None, c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=taps, pro=0,
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
                            scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if (s8mode != 1 and epi != 3) else None, out_s8=o8.data_ptr() if o8 is not None else None,
                            out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,
                            cvec=cvec.data_ptr() if cvec is not None else None, cvec_ld=cout if cvec is not None else 0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
                            korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0),
                            qkv=ct.addressof(qkv) if qkv is not None else None)
-            runs.append((name, ctx, "vh_conv", a, knobs, (s8, wt, qkv, (Q, K, V) if epi == 3 else None, o8, out, o8 if s8mode == 1 else out)))   # (every buffer the launch writes stays referenced)
+            runs.append((name, ctx, "vh_conv", a, knobs, (s8, s81, wt, qkv, (Q, K, V) if epi == 3 else None, o8, out, o8 if s8mode == 1 else out)))   # (every buffer the launch writes stays referenced)
 
     def launch(r, k):
         name, ctx, op, a, knobs, _ = r

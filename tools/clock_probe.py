@@ -82,3 +82,21 @@ if kind == "conv":
           f"launch time / workgroups per CU = {per_tile_us:.2f} us -> unaccounted (store drain, dispatch) {per_tile_us - (np.median(d[:, 0]) + np.median(d[:, 2]) + np.median(d[:, 3])) / clk / 1e3:.2f} us")
     print("  epilogue, wave 0: cumulative us after each of its 32x32 blocks:", " ".join(f"{np.median(d[:, 4 + b]) / clk / 1e3:.2f}" for b in range(6)))
     print(f"  prologue, wave 0: index math {np.median(d[:, 10]) / clk / 1e3:.2f} us, first DMA issue + landing {np.median(d[:, 11]) / clk / 1e3:.2f} us")
+    if os.environ.get("TILE") == "8" and os.environ.get("PLACEMENT"):
+        # which workgroup ids share a CU, and how far apart their K loops start (100 MHz ticks): HW_ID / XCC_ID logged by the -DVH_CLOCK build
+        raw = dbg.cpu().numpy().reshape(-1, W)
+        place = {}
+        for wg in range(min(len(raw), 2048)):
+            hw, xcc = int(raw[wg, 6]), int(raw[wg, 7]) & 0xF
+            if raw[wg, 1] <= 0:
+                continue
+            key = (xcc, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 15)
+            place.setdefault(key, []).append((int(raw[wg, 8]), int(raw[wg, 9]), wg))
+        print(f"  placement: {len(place)} distinct (xcc, se, sh, cu) among the first 2048 workgroups")
+        for key in sorted(place)[:6]:
+            v = sorted(place[key])
+            t0 = v[0][0]
+            print("   ", key, " ".join(f"wg{wg}:[{a - t0},{b - t0}]" for a, b, wg in v[:8]))
+    if os.environ.get("TILE") == "8":      # conv_x3_patch (CLOCK_LIB = a -DVH_CLOCK variant of conv_patch.hip): slots 4 / 5 hold sums over the K loop
+        print(f"  patch kernel, wave 0: chunk-boundary patch reloads {np.median(d[:, 4]) / clk / 1e3:.2f} us, per-K-tile wait + barrier {np.median(d[:, 5]) / clk / 1e3:.2f} us "
+              f"(both inside the K loop's {np.median(d[:, 0]) / clk / 1e3:.2f} us)")

@@ -6,8 +6,8 @@ std::string& vh_err() {
     return e;
 }
 
-static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0, 1, -1, -1, 1, 1, -1, 60, 0};
-static const char* const g_knob_names[VH_NUM_KNOBS] = {"attn_xcd", "dbg_lo", "dbg_hi", "attn_m16", "conv_korder", "conv_stagger", "attn_pipe", "attn_nomax", "conv_slim2", "conv_korder_mb", "conv_ksplit"};
+static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0, 1, -1, -1, 1, 1, -1, 60, 0, -1, 0};
+static const char* const g_knob_names[VH_NUM_KNOBS] = {"attn_xcd", "dbg_lo", "dbg_hi", "attn_m16", "conv_korder", "conv_stagger", "attn_pipe", "attn_nomax", "conv_slim2", "conv_korder_mb", "conv_ksplit", "conv_patch", "conv_patch_delay"};
 
 int vh_knob(int id) { return (id >= 0 && id < VH_NUM_KNOBS) ? g_knobs[id] : 0; }
 
@@ -24,7 +24,8 @@ extern "C" int vh_abi_version(void) { return VH_ABI_VERSION; }
 int vh_diag_conv3();
 int vh_diag_conv1();
 int vh_diag_attn();
-extern "C" int vh_diag_flags(void) { return VH_DIAG_FLAG | (vh_diag_conv3() << 1) | (vh_diag_conv1() << 2) | (vh_diag_attn() << 3); }
+int vh_diag_conv_patch();
+extern "C" int vh_diag_flags(void) { return VH_DIAG_FLAG | (vh_diag_conv3() << 1) | (vh_diag_conv1() << 2) | (vh_diag_attn() << 3) | (vh_diag_conv_patch() << 4); }
 
 extern "C" const char* vh_last_error(void) { return vh_err().c_str(); }
 

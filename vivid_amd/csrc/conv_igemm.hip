@@ -260,7 +260,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     VH_REQUIRE(a.epi >= VH_EPI_STORE && a.epi <= VH_EPI_QKV, "vh_conv: bad epilogue");
     VH_REQUIRE(a.stagger >= 0 && a.stagger <= 2, "vh_conv: stagger must be 0, 1 or 2");
     VH_REQUIRE(a.korder >= VH_KORDER_AUTO && a.korder <= VH_KORDER_CHUNK, "vh_conv: korder must be VH_KORDER_AUTO, _TAP or _CHUNK");
-    VH_REQUIRE((a.tile >= VH_TILE_AUTO && a.tile <= VH_TILE_256x64) || a.tile == VH_TILE_256x192, "vh_conv: tile must be one of VH_TILE_*");
+    VH_REQUIRE((a.tile >= VH_TILE_AUTO && a.tile <= VH_TILE_256x64) || a.tile == VH_TILE_256x192 || a.tile == VH_TILE_PATCH16, "vh_conv: tile must be one of VH_TILE_*");
     VH_REQUIRE(a.tile != VH_TILE_256x192 || a.taps == 9, "vh_conv: VH_TILE_256x192 exists for 3x3 convolutions only");
     VH_REQUIRE(a.tile == VH_TILE_AUTO || a.kernel == VH_CONV_GLDS256, "vh_conv: a forced tile shape exists only for VH_CONV_GLDS256");
     if (a.epi == VH_EPI_QKV) {
@@ -290,6 +290,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.M = (int)M; k.HW = a.h * a.w; k.NT = (int)NT;
     k.div_hw = fastdiv_make((unsigned)(a.h * a.w)); k.div_w = fastdiv_make((unsigned)a.w); k.div_c0u = fastdiv_make((unsigned)(a.c0 / 4));
     k.ksplit = 1; k.scratch = nullptr; k.korder = 0; k.stagger = 0; k.dbg = nullptr;
+    k.ptx = k.pty = 0; k.div_ptx = k.div_ptiles = fastdiv_make(1);
     k.q = nullptr; k.qk = k.qv = nullptr; k.q_heads = k.q_nj = k.q_rows_per_b = k.q_koff = k.q_klp = 0; k.q_d = 64; k.q_scale = 1.f;
     if (a.epi == VH_EPI_QKV) {
         const vh_qkv_epilogue& e = *a.qkv;

@@ -1,0 +1,435 @@
+// bf16x3 3x3 convolution for Cout <= 64 with the input PATCH resident in LDS (gfx950).
+//
+// Same operation and epilogues as conv_x3_glds (reference training/models.py:123-126, F.conv2d(x, w, padding=1), with the fused
+// y*c + mp_silu :175-176 / mp_sum + clip :184,:204 epilogues); this is the kernel of the full-resolution 64-channel layers of the
+// super-resolution UNet (SRXAttnUNet :575-582 at 256x256 / 1024x1024), where conv_x3_glds' 256x64 tile is bound by OPERAND DELIVERY, not
+// by the matrix pipe: per 32-channel K-tile it moves 32 KB of activations + 8 KB of weights L2 -> LDS for 768 CU-cycles of MFMA work
+// (104 GB/s per CU at full MFMA rate against the ~70 GB/s a CU gathers from L2, MI355X_MICROARCH.md "Indexed rows: gather into LDS"),
+// because every input pixel is staged nine times, once per tap.
+//
+// Here one workgroup owns a 16x16-pixel output tile of one image.  Per 32-channel chunk its (16+2)x(16+2) input patch is staged ONCE
+// (41 KB, LDS-DMA) and the nine taps read their A fragments from it in place - a tap is a constant offset into the patch - so the
+// activations cross L2 -> LDS 1.27x instead of 9x; the weights stream through two 8 KB stages as before.  58 KB of LDS and <= 128
+// VGPRs: two workgroups per CU, one's patch loads / epilogue run under the other's MFMAs.
+//   patch image : [pixel p = py*18 + px][8 units of 16 B], unit order hl*4 + chunk, unit' = unit ^ (p & 7) applied on the SOURCE side
+//                 of the DMA; with that swizzle the 16-pixel ds_read_b128 fragment reads are conflict-free for all three dx
+//                 alignments (brute-forced over the instruction's four 16-lane groups; (p>>1)&7, conv_x3_glds' swizzle, is 2-way
+//                 conflicted whenever the row of 16 pixels does not start at a multiple of 4)
+//   wave w      : output rows 2w, 2w+1 of the tile (two 16-pixel M tiles) x 64 output channels: 24 MFMAs per K-tile
+//   K order     : chunk-major (the nine taps of channels 0-31, then of 32-63, ...) - different from both orders of conv_x3_glds only in
+//                 rounding (fp32 accumulation order)
+//   tail segment: the 1-tap second source of a fused conv_res1 + conv_skip (vh_conv_args.src1) needs no halo and no reuse across
+//                 taps: it runs conv_x3_glds' loop (a 256-pixel A tile per K-tile, two LDS stages) in the space of the patch.  (A first
+//                 form loaded its A fragments global -> registers, 32 contiguous bytes per lane: 16 different lines per 16 lanes, paced
+//                 by the vector L1's tag rate - +3..10 % where the staged form's main loop gives +20..25 %.)
+#include "conv_common.h"
+#include <type_traits>
+
+namespace {
+using namespace vhconv;
+
+constexpr int PT = 16, PP = PT + 2, PPIX = PP * PP;        // tile edge, patch pitch, patch pixels (324)
+constexpr int PSLOTS = 41 * 64;                             // 16-byte LDS slots of the patch: 324*8 = 2592, rounded up to whole wave-instructions (2624)
+
+__device__ __forceinline__ void glds16p(const float4* gsrc, unsigned lds_addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_addr) : "memory", "m0");
+#endif
+}
+__device__ __forceinline__ void wait_dma_p() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// all but the N youngest vector-memory operations of this wave have completed (they complete in issue order)
+template <int N>
+__device__ __forceinline__ void wait_dma_but() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+#endif
+}
+
+// residual (MPSUM) / cvec (SCALE_SILU) values of one 32-pixel x 32-channel block, requested ahead of its read-out
+struct PAux { float4 v[4]; float rs[4]; };
+
+// Block = the wave's two image rows (yb, yb+1) x 16 pixels from x0, channels c0..c0+31.  Lane (cg = lane&7, rsub = lane>>3) handles 4
+// consecutive channels of pixels rl = rsub + 8i, i = 0..3: image row yb + (i>>1), column x0 + rsub + 8*(i&1).
+template <int EPI>
+__device__ __forceinline__ PAux patch_prefetch(const ConvK& a, int img, int yb, int x0, int c0, int lane) {
+    PAux x;
+    const int cg = lane & 7, rsub = lane >> 3, gn = c0 + 4 * cg;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        x.rs[i] = 0.f;
+        const int yy = yb + (i >> 1), xx = x0 + rsub + 8 * (i & 1);
+        if (EPI == VH_EPI_MPSUM) {
+            if (yy < a.h && xx < a.w) {
+                const size_t gm = ((size_t)img * a.h + yy) * a.w + xx;
+                x.v[i] = *reinterpret_cast<const float4*>(a.res + gm * a.cout + gn);
+                x.rs[i] = a.res_scale ? a.ta * a.res_scale[gm] : a.ta;
+            }
+        } else if (EPI == VH_EPI_SCALE_SILU) {
+            if (i == 0) x.v[0] = *reinterpret_cast<const float4*>(a.cvec + (size_t)img * a.cvec_ld + gn);      // one image per tile: one row of cvec
+        }
+    }
+    return x;
+}
+
+template <int EPI>
+__device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00, const f32x4 t01, const f32x4 t10, const f32x4 t11,
+                                                int img, int yb, int x0, int c0, float* patch, int lane, const PAux& aux) {
+    constexpr int LD = 36;
+    {
+        const int c = lane & 15, rb = (lane >> 4) * 4;      // C/D map of the 16x16 MFMA: column = lane&15, row = 4*(lane>>4) + reg
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            patch[(rb + r) * LD + c] = t00[r];
+            patch[(rb + r) * LD + 16 + c] = t01[r];
+            patch[(16 + rb + r) * LD + c] = t10[r];
+            patch[(16 + rb + r) * LD + 16 + c] = t11[r];
+        }
+    }
+    const int cg = lane & 7, rsub = lane >> 3;
+    const int sub = 4 * (cg & 1);                             // position of the lane's 4 channels inside their 8-channel S8 chunk
+    const bool odd = sub != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&patch[(rsub + 8 * i) * LD + 4 * cg]);
+        float y[4] = {v.x, v.y, v.z, v.w};
+        if (EPI == VH_EPI_SCALE_SILU) {
+            const float c[4] = {aux.v[0].x, aux.v[0].y, aux.v[0].z, aux.v[0].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = mp_silu_dev(y[j] * c[j]);
+        } else if (EPI == VH_EPI_MPSUM) {
+            const float rv[4] = {aux.v[i].x, aux.v[i].y, aux.v[i].z, aux.v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = rv[j] * aux.rs[i] + y[j] * a.tb;
+                if (a.clip > 0.f) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
+            }
+        } else if (a.clip > 0.f) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = fminf(fmaxf(y[j], -a.clip), a.clip);
+        }
+        const int yy = yb + (i >> 1), xx = x0 + rsub + 8 * (i & 1);
+        const bool ok = yy < a.h && xx < a.w;                  // (ragged image edges: the tile hangs over)
+        const size_t eo = (((size_t)img * a.h + yy) * a.w + xx) * a.cout + c0 + 4 * cg;
+        if (a.out && ok) *reinterpret_cast<float4*>(a.out + eo) = make_float4(y[0], y[1], y[2], y[3]);
+        if (a.out_s8) {
+            // the lane pair (even, odd) holds the two halves of one 8-channel chunk [hi x8 | lo x8]: swap one 8-byte piece so that the even
+            // lane writes the whole hi half and the odd lane the whole lo half - one 16-byte store each (conv_common.h s8_store_half_chunk)
+            unsigned h[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h[j] = bf16_rn_bits(y[j]);
+                lo[j] = bf16_rn_bits(y[j] - __uint_as_float(h[j] << 16));
+            }
+            const unsigned H0 = h[0] | (h[1] << 16), H1 = h[2] | (h[3] << 16), L0 = lo[0] | (lo[1] << 16), L1 = lo[2] | (lo[3] << 16);
+            const unsigned r0 = __shfl_xor(odd ? H0 : L0, 1), r1 = __shfl_xor(odd ? H1 : L1, 1);
+            if (ok) *reinterpret_cast<uint4*>(a.out_s8 + (eo - sub) * 2 + (odd ? 8 : 0)) = odd ? make_uint4(r0, r1, L0, L1) : make_uint4(H0, H1, r0, r1);
+        }
+    }
+}
+
+// PF: the next chunk's patch is requested during this chunk's taps (two pieces by LDS-DMA into a landing pad, three into registers - the
+// loop cannot hold all five) and moved into place at the boundary, instead of being fetched there.  Same-device A/B: the boundary itself
+// shrinks from 2.0 to 0.45 us (s_memtime stamps), worth +3 % with two chunks (64 input channels: one boundary, short K loop) and -2.5 %
+// with four or six (the extra LDS traffic and the address work sit in a K loop that is MFMA-paced while both workgroups of the CU are in
+// theirs): the launcher takes it for cin_pad <= 64 only.
+template <bool TAIL, bool PF>
+__global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
+    // One LDS region for activations: the resident patch (PSLOTS 16-byte slots, 41 KB) and, behind it, the landing pad of the next chunk's
+    // LDS-DMA pieces (PF); the TAIL variant re-uses the whole region as two 32 KB stages of its 1-tap segment (80 KB with the
+    // weights: exactly half a CU's LDS) - and the epilogue as eight per-wave transpose patches.
+    constexpr int PXL = 2;                                   // next chunk's pieces 0..PXL-1 (and wave 0's sixth) go through the landing pad, the rest through registers
+    constexpr int XSLOTS = PXL * 512 + 64;
+    constexpr int ASLOTS = TAIL ? 4096 : PSLOTS + (PF ? XSLOTS : 0);
+    static_assert(PSLOTS + XSLOTS <= 4096, "landing pad must fit behind the patch");
+    __shared__ float4 sA[ASLOTS];
+    __shared__ float4 sB[2][64 * 8];                         // weight K-tiles, two stages (16 KB)
+    float4* const sP = sA;
+    float4* const sX = sA + PSLOTS;
+    (void)sX;
+
+#ifdef VH_CLOCK   // diagnostic build (make variant ... DEFS=-DVH_CLOCK=1; tools/clock_probe.py): s_memtime stamps of wave 0 into vh_debug_ptr()
+#define PCK(var) const unsigned long long var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+    PCK(ck_e0);
+    unsigned long long ck_bsum = 0, ck_ksum = 0;
+#endif
+    // Desynchronise the two workgroups of a CU (knob "conv_patch_delay", a.stagger = units of 2048 cycles): both start together and would
+    // run in lock step - both in their prologue, both in their K loop sharing the matrix pipe, both in their epilogue.  The second
+    // workgroup of every CU in the launch's first round (ids 256..511 under round-robin placement; a guess that costs nothing where it is
+    // wrong) starts late, so that one's patch loads / stores run under the other's MFMAs from then on.
+    if (a.stagger > 0 && blockIdx.x >= 256u && blockIdx.x < 512u)
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
+    const int t = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+    const unsigned tile = xcd_tile_id();
+    const int img = fastdiv((int)tile, a.div_ptiles);
+    const int trem = (int)tile - img * (a.pty * a.ptx);
+    const int tyi = fastdiv(trem, a.div_ptx), txi = trem - tyi * a.ptx;
+    const int y0 = tyi * PT, x0 = txi * PT;
+    const float4* zp = reinterpret_cast<const float4*>(a.zeros);
+
+    // ---- patch staging map: slot = j*512 + t -> pixel p = slot>>3 (py = p/18, px = p%18), LDS unit u' = slot&7 holds logical unit u' ^ (p&7)
+    // rounds j = 0..4 cover slots 0..2559 with all eight waves; slots 2560..2623 (pixels 320..323 + padding) are wave 0's sixth piece
+    constexpr int PR = 6;
+    // Source of piece j of this thread for the chunk at 16-byte-unit offset cu: recomputed whenever a chunk is requested (~12 VALU per piece,
+    // once per nine K-tiles) instead of held across the K loop - the loop has no registers to spare (<= 128 for two workgroups per CU).
+    const float4* src4 = reinterpret_cast<const float4*>(a.src0);
+    const unsigned cu4 = (unsigned)(a.c0 >> 2);                        // 16-byte units per pixel
+    const unsigned img_off = (unsigned)img * (unsigned)a.HW;
+    auto piece_src = [&](int j, unsigned cu, int tq) __attribute__((always_inline)) -> const float4* {
+        // tq == threadIdx.x, passed through an opaque copy by the callers inside the K loop: otherwise hipcc hoists this whole computation
+        // out of the loop and keeps its results live (LICM), which is exactly the register cost it is here to avoid
+        const int slot = j * 512 + (j == PR - 1 ? (tq & 63) : tq);       // (the sixth piece exists for wave 0 only: its lane id is its slot offset)
+        const int p = slot >> 3, up = slot & 7;
+        const int py = (p * 3641) >> 16, px = p - py * PP;                  // p / 18 for p < 4096
+        const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+        const bool inside = p < PPIX && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+        const int u = up ^ (p & 7), s8u = (u & 3) * 2 + (u >> 2);          // LDS unit order hl*4 + chunk -> S8 order chunk*2 + hl
+        // 32-bit offsets in 16-byte units (the dispatcher checks M * c0 / 4 < 2^32)
+        return inside ? src4 + (size_t)((img_off + (unsigned)(yy * a.w + xx)) * cu4 + (unsigned)s8u + cu) : zp;
+    };
+    unsigned ldsP_w = 0, ldsB_w = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    ldsP_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sP[w * 64]);
+    ldsB_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sB[0][w * 64]);
+#endif
+    auto load_patch = [&](int cu) __attribute__((always_inline)) {          // cu: channel offset in 16-byte units
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+#pragma unroll
+        for (int j = 0; j < PR - 1; ++j) glds16p(piece_src(j, (unsigned)cu, tq), ldsP_w + j * 8192u);
+        if (w == 0) glds16p(piece_src(PR - 1, (unsigned)cu, tq), ldsP_w + (PR - 1) * 8192u);
+    };
+
+    // ---- weight staging (as conv_x3_glds): row = output channel w*8 + (l>>3), LDS unit l&7, swizzle (row>>1)&7 on the source side
+    const int KU = a.k_pad >> 2;
+    const int gnB = w * 8 + (l >> 3);
+    const int uslotB = (l & 7) ^ (((w & 1) << 2) | (l >> 4));
+    const int uB = (uslotB & 3) * 2 + (uslotB >> 2);
+    const bool bzero = gnB >= a.cout;
+    const float4* pbB = bzero ? zp : a.wt + (size_t)gnB * KU + uB;
+    auto issueB = [&](int st, int ku) __attribute__((always_inline)) { glds16p(bzero ? zp : pbB + ku, ldsB_w + (unsigned)st * 8192u); };
+
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+    const int l15 = l & 15, kg = l >> 4;
+    const int pbase0 = (2 * w + 1) * PP + l15 + 1;             // patch pixel of (tile row 2w, column l15) for the centre tap; row 2w+1 is PP further
+    const int brow16 = l15 * 8, u16h = kg ^ (l15 >> 1), u16l = (4 + kg) ^ (l15 >> 1);
+
+    auto mfma3 = [&](f32x4& c, const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl) __attribute__((always_inline)) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+    };
+    // one K-tile: tap offset `off` (patch pixels) of the resident chunk against weight stage st
+    auto compute = [&](int st, int off) __attribute__((always_inline)) {
+        // A fragments of both M tiles first (16 registers), then one N tile of weights at a time (8): the all-B-first order of conv_x3_glds
+        // holds 32 registers of weights, which this kernel needs for the next chunk's patch (PF)
+        bf16x8 ah[2], al[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = pbase0 + i * PP + off;
+            const int ih = p * 8 + (kg ^ (p & 7));
+            ah[i] = *reinterpret_cast<const bf16x8*>(&sP[ih]);
+            al[i] = *reinterpret_cast<const bf16x8*>(&sP[ih ^ 4]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
+        }
+    };
+
+    // ---- main loop: chunks of 32 channels; per chunk the patch is staged once and the nine taps run against it -------------------------
+    const int nch = a.cin_pad >> 5;
+    const int ntail = TAIL ? (a.c1 >> 5) : 0;
+#ifdef VH_CLOCK
+    PCK(ck_p1);
+#endif
+    load_patch(0);
+    issueB(0, 0);
+    wait_dma_p();
+    __syncthreads();
+#ifdef VH_CLOCK
+    PCK(ck_m0);
+    const unsigned long long ck_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+    int st = 0;
+    f32x4 nx[PR - 1 - PXL];                                    // PF: the next chunk's register-staged pieces of this thread, requested at tap 0 of the chunk before
+    unsigned ldsX_w = 0, ldsX6 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (PF) {
+        ldsX_w = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sX[w * 64]);
+        ldsX6 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)&sX[PXL * 512]);
+    }
+#endif
+    for (int c = 0; c < nch; ++c) {
+        if (c > 0) {                                           // (the last barrier of the previous chunk retired every read of its patch)
+#ifdef VH_CLOCK
+            PCK(ck_b0);
+#endif
+            if constexpr (PF) {
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) sP[j * 512 + t] = sX[j * 512 + t];   // (each thread moves the slots its own DMA filled; waited for by tap 1's vmcnt(0))
+#pragma unroll
+                for (int j = PXL; j < PR - 1; ++j) *reinterpret_cast<f32x4*>(&sP[j * 512 + t]) = nx[j - PXL];
+                if (w == 0) sP[(PR - 1) * 512 + l] = sX[PXL * 512 + l];
+            } else {
+                load_patch(c * 8);
+                wait_dma_p();
+            }
+            __syncthreads();
+#ifdef VH_CLOCK
+            PCK(ck_b1);
+            ck_bsum += ck_b1 - ck_b0;
+#endif
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            // weights of the next K-tile: next tap of this chunk, tap 0 of the next chunk, or the first tail tile
+            if (tap < 8) issueB(st ^ 1, ((tap + 1) * a.cin_pad + c * 32) >> 2);
+            else if (c + 1 < nch) issueB(st ^ 1, ((c + 1) * 32) >> 2);
+            else if (TAIL && ntail > 0) issueB(st ^ 1, (9 * a.cin_pad) >> 2);
+            const bool pf = PF && tap == 0 && c + 1 < nch;
+            if (pf) {
+                // plain loads, behind this K-tile's weight DMA in the wave's (in-order) memory queue: the tile waits for all but these
+                const unsigned cu = (unsigned)(c + 1) * 8u;
+                int tq = t;
+                asm volatile("" : "+v"(tq));
+#pragma unroll
+                for (int j = 0; j < PXL; ++j) glds16p(piece_src(j, cu, tq), ldsX_w + j * 8192u);
+                if (w == 0) glds16p(piece_src(PR - 1, cu, tq), ldsX6);
+#pragma unroll
+                for (int j = PXL; j < PR - 1; ++j) nx[j - PXL] = *reinterpret_cast<const f32x4*>(piece_src(j, cu, tq));
+            }
+            compute(st, dy * PP + dx);
+#ifdef VH_CLOCK
+            PCK(ck_k0);
+#endif
+            if (pf) wait_dma_but<PR - 1 - PXL>();              // (the register-staged loads are the youngest; the LDS-DMA pieces before them are waited for with the weights)
+            else wait_dma_p();
+            __syncthreads();
+#ifdef VH_CLOCK
+            PCK(ck_k1);
+            ck_ksum += ck_k1 - ck_k0;
+#endif
+            st ^= 1;
+        }
+    }
+    if constexpr (TAIL) {
+        // 1-tap tail over the second source (c1 channels, same 256 pixels, no halo): conv_x3_glds' loop - per K-tile a 256-row x 32-channel
+        // A tile (row r = tile pixel (r>>4, r&15), swizzle r&7) and a weight tile staged by LDS-DMA into the stage not being read.
+        if (ntail > 0) {
+            const float4* s14 = reinterpret_cast<const float4*>(a.src1);
+            const unsigned c14 = (unsigned)(a.c1 >> 2);
+            unsigned to[4], tin = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int r = j * 64 + (t >> 3), up = t & 7;
+                const int yy = y0 + (r >> 4), xx = x0 + (r & 15);
+                const bool inside = yy < a.h && xx < a.w;
+                const int u = up ^ (r & 7), s8u = (u & 3) * 2 + (u >> 2);
+                to[j] = inside ? (img_off + (unsigned)(yy * a.w + xx)) * c14 + (unsigned)s8u : 0u;
+                tin |= inside ? (1u << j) : 0u;
+            }
+            auto issueA = [&](int sa, unsigned cu) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) glds16p(((tin >> j) & 1u) ? s14 + (size_t)(to[j] + cu) : zp, ldsP_w + (unsigned)sa * 32768u + j * 8192u);
+            };
+            issueA(0, 0u);                                     // (the main loop's last barrier retired every read of the patch; tile 0's weights are already in sB[st])
+            wait_dma_p();
+            __syncthreads();
+            const int rbase = (2 * w) * 16 + l15;
+            for (int c = 0; c < ntail; ++c) {
+                const int sa = c & 1;
+                if (c + 1 < ntail) {
+                    issueB(st ^ 1, (9 * a.cin_pad + (c + 1) * 32) >> 2);
+                    issueA(sa ^ 1, (unsigned)(c + 1) * 8u);
+                }
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int r = rbase + i * 16;
+                    const int ih = sa * 2048 + r * 8 + (kg ^ (r & 7));
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&sA[ih]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&sA[ih ^ 4]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
+                }
+                wait_dma_p();
+                __syncthreads();
+                st ^= 1;
+            }
+        }
+    }
+#ifdef VH_CLOCK
+    PCK(ck_m1);
+    const unsigned long long ck_r1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    unsigned long long* dbg = a.dbg && blockIdx.x < 16384u && t == 0 ? a.dbg + (size_t)blockIdx.x * 12 : nullptr;
+    if (dbg) { dbg[0] = ck_m1 - ck_m0; dbg[1] = ck_r1 - ck_r0; dbg[2] = ck_m0 - ck_e0; dbg[10] = ck_p1 - ck_e0; dbg[11] = ck_m0 - ck_p1;
+               dbg[4] = ck_bsum; dbg[5] = ck_ksum;
+               dbg[6] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID: wave [3:0], simd [5:4], pipe [7:6], cu [11:8], sh [12], se [15:13]
+               dbg[7] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+               dbg[8] = ck_r0; dbg[9] = ck_r1; }
+#endif
+    // ---- epilogue: the wave's two 32x32 blocks through its LDS transpose patch (the loop's last barrier retired every read of sP) ----
+    float* patch = reinterpret_cast<float*>(&sP[0]) + w * (32 * 36);
+    const int yb = y0 + 2 * w;
+    if (yb >= a.h) return;
+    // (the lane id re-derived from the hardware counter: carried over from the prologue it costs the K loop a register it does not have)
+    const int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    auto run = [&](auto epic) __attribute__((always_inline)) {
+        constexpr int EPI = decltype(epic)::value;
+        PAux cur = patch_prefetch<EPI>(a, img, yb, x0, 0, le);
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            PAux nxt = cur;
+            if (ni == 0) nxt = patch_prefetch<EPI>(a, img, yb, x0, 32, le);
+            patch_block_out<EPI>(a, acc[0][2 * ni], acc[0][2 * ni + 1], acc[1][2 * ni], acc[1][2 * ni + 1], img, yb, x0, ni * 32, patch, le, cur);
+            cur = nxt;
+        }
+    };
+    if (a.epi == VH_EPI_MPSUM) run(std::integral_constant<int, VH_EPI_MPSUM>{});
+    else if (a.epi == VH_EPI_SCALE_SILU) run(std::integral_constant<int, VH_EPI_SCALE_SILU>{});
+    else run(std::integral_constant<int, VH_EPI_STORE>{});
+#ifdef VH_CLOCK
+    { PCK(ck_x); if (dbg) dbg[3] = ck_x - ck_m1; }
+#endif
+}
+
+}  // namespace
+
+int vh_diag_conv_patch() { return VH_DIAG_FLAG; }
+
+// Launch of the patch-resident kernel (arguments validated by vh_conv / chosen by vh_conv_x3_glds_dispatch): 3x3, no `up`, cout == 64,
+// epilogue STORE / SCALE_SILU / MPSUM without res_up.  One workgroup per 16x16 output tile per image.
+void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
+    k.ptx = (k.w + PT - 1) / PT;
+    k.pty = (k.h + PT - 1) / PT;
+    k.div_ptx = vhconv::fastdiv_make((unsigned)k.ptx);
+    k.div_ptiles = vhconv::fastdiv_make((unsigned)(k.ptx * k.pty));
+    const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty);
+    const bool pf = k.cin_pad <= 64;
+    if (k.c1 > 0) { if (pf) hipLaunchKernelGGL((conv_x3_patch<true, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<true, false>), dim3(grid), dim3(512), 0, s, k); }
+    else { if (pf) hipLaunchKernelGGL((conv_x3_patch<false, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<false, false>), dim3(grid), dim3(512), 0, s, k); }
+}

@@ -629,9 +629,29 @@ int vh_diag_conv1() { return VH_DIAG_FLAG; }
 #endif
 #if VH_CONV_TU != 1
 int vh_diag_conv3() { return VH_DIAG_FLAG; }
+void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s);      // conv_patch.hip
 // Entry used by vh_conv for prec == VH_PREC_BF16X3 && kernel == VH_CONV_GLDS (arguments already validated).
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
+    {
+        // Patch-resident kernel (conv_patch.hip) for the 3x3 Cout == 64 layers: one workgroup per 16x16-pixel tile per image.
+        // (the kernel addresses its input through 32-bit offsets in 16-byte units: M * c0 / 4 < 2^32)
+        const bool patch_ok = a.taps == 9 && !a.up && a.cout == 64 && a.epi != VH_EPI_QKV && !(a.epi == VH_EPI_MPSUM && a.res_up) &&
+                              (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0;
+        if (a.tile == VH_TILE_PATCH16 && !patch_ok)
+            return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up` / res_up, cout == 64 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
+        const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
+        const int pknob = vh_knob(VH_KNOB_CONV_PATCH);
+        const bool patch = patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && ptiles >= 512))));
+        if (patch) {
+            if (ptiles >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
+            k.ksplit = 1; k.scratch = nullptr; k.korder = 1; k.stagger = vh_knob(VH_KNOB_CONV_PATCH_DELAY); k.dbg = vh_debug_ptr();
+            return vh_dispatch(ctx, VH_TAG_CONV3, flops, bytes, [k](hipStream_t s) -> int {
+                vh_conv_x3_patch_launch(k, s);
+                return vh_check_launch("conv_x3_patch");
+            });
+        }
+    }
     // 256x256 tiles when Cout allows it and the grid still gives every CU (256) a workgroup; otherwise 256x128
     // (round 3, late: from 128 workgroups on when the K loop is long - 216+ K-tiles: half a round of the bigger wave tile then beats a full
     //  round of 256x128 tiles by 3..11 %, growing with K; at 108-144 K-tiles it loses 1..8 %; profiles/r03_ab_conv_tile_choice_small_launches.txt)

@@ -48,7 +48,9 @@ enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATT
        VH_KNOB_CONV_SLIM2 = 8,       // -1 (default): Cout <= 64 layers take the 256x64 two-per-CU tile; 0: the 512x64 one (A/B runs)
        VH_KNOB_CONV_KORDER_MB = 9,   // input size (MB) above which 3x3 convolutions take the chunk-major K order (default 60)
        VH_KNOB_CONV_KSPLIT = 10,     // > 0: force this many K slices in the glds convolutions (A/B runs of the split-K rule)
-       VH_NUM_KNOBS = 11 };
+       VH_KNOB_CONV_PATCH = 11,      // -1 (default): 3x3 Cout == 64 layers at large M take the patch-resident kernel (conv_patch.hip); 0 never; 1 whenever eligible
+       VH_KNOB_CONV_PATCH_DELAY = 12, // conv_x3_patch: start delay (units of 2048 shader cycles) of the second workgroup per CU in a launch's first round
+       VH_NUM_KNOBS = 13 };
 int vh_knob(int id);
 // device buffer for the stamps of diagnostic builds (-DVH_CLOCK), set through the knobs "dbg_lo"/"dbg_hi"; null otherwise
 inline unsigned long long* vh_debug_ptr() {
