@@ -137,8 +137,13 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
 // shrinks from 2.0 to 0.45 us (s_memtime stamps), worth +3 % with two chunks (64 input channels: one boundary, short K loop) and -2.5 %
 // with four or six (the extra LDS traffic and the address work sit in a K loop that is MFMA-paced while both workgroups of the CU are in
 // theirs): the launcher takes it for cin_pad <= 64 only.
-template <bool TAIL, bool PF>
+// NJ: 16-channel N tiles per wave - 4 (Cout <= 64) or 8 (Cout <= 128: 64 accumulator registers, 16 KB weight stages, 73 KB of LDS).
+template <int NJ, bool TAIL, bool PF>
 __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
+    static_assert(NJ == 4 || NJ == 8, "64 or 128 output channels per workgroup");
+    static_assert(!(TAIL && NJ == 8), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
+    static_assert(!(PF && NJ == 8), "the landing pad of the next chunk's pieces and 32 KB of weight stages do not fit half a CU's LDS");
+    constexpr int BN = NJ * 16, RB = BN / 64;                // output channels per workgroup; weight DMA pieces per wave and K-tile
     // One LDS region for activations: the resident patch (PSLOTS 16-byte slots, 41 KB) and, behind it, the landing pad of the next chunk's
     // LDS-DMA pieces (PF); the TAIL variant re-uses the whole region as two 32 KB stages of its 1-tap segment (80 KB with the
     // weights: exactly half a CU's LDS) - and the epilogue as eight per-wave transpose patches.
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     constexpr int ASLOTS = TAIL ? 4096 : PSLOTS + (PF ? XSLOTS : 0);
     static_assert(PSLOTS + XSLOTS <= 4096, "landing pad must fit behind the patch");
     __shared__ float4 sA[ASLOTS];
-    __shared__ float4 sB[2][64 * 8];                         // weight K-tiles, two stages (16 KB)
+    __shared__ float4 sB[2][BN * 8];                         // weight K-tiles, two stages (16 / 32 KB)
     float4* const sP = sA;
     float4* const sX = sA + PSLOTS;
     (void)sX;
@@ -165,7 +170,10 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
         for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(32);
     const int t = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
-    const unsigned tile = xcd_tile_id();
+    // workgroup -> (pixel tile, block of BN output channels): the N blocks of one pixel tile are neighbours (they stage the same patch: L2)
+    const unsigned tile0 = xcd_tile_id();
+    const int nb = a.NT > 1 ? (int)(tile0 % (unsigned)a.NT) : 0;
+    const unsigned tile = a.NT > 1 ? tile0 / (unsigned)a.NT : tile0;
     const int img = fastdiv((int)tile, a.div_ptiles);
     const int trem = (int)tile - img * (a.pty * a.ptx);
     const int tyi = fastdiv(trem, a.div_ptx), txi = trem - tyi * a.ptx;
@@ -207,18 +215,24 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
     // ---- weight staging (as conv_x3_glds): row = output channel w*8 + (l>>3), LDS unit l&7, swizzle (row>>1)&7 on the source side
     const int KU = a.k_pad >> 2;
-    const int gnB = w * 8 + (l >> 3);
     const int uslotB = (l & 7) ^ (((w & 1) << 2) | (l >> 4));
     const int uB = (uslotB & 3) * 2 + (uslotB >> 2);
-    const bool bzero = gnB >= a.cout;
-    const float4* pbB = bzero ? zp : a.wt + (size_t)gnB * KU + uB;
-    auto issueB = [&](int st, int ku) __attribute__((always_inline)) { glds16p(bzero ? zp : pbB + ku, ldsB_w + (unsigned)st * 8192u); };
+    const float4* pbB[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int gnB = nb * BN + j * 64 + w * 8 + (l >> 3);
+        pbB[j] = gnB >= a.cout ? nullptr : a.wt + (size_t)gnB * KU + uB;
+    }
+    auto issueB = [&](int st, int ku) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) glds16p(pbB[j] ? pbB[j] + ku : zp, ldsB_w + (unsigned)st * (unsigned)(BN * 128) + j * 8192u);
+    };
 
-    f32x4 acc[2][4];
+    f32x4 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
@@ -236,15 +250,17 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
         // A fragments of both M tiles first (16 registers), then one N tile of weights at a time (8): the all-B-first order of conv_x3_glds
         // holds 32 registers of weights, which this kernel needs for the next chunk's patch (PF)
         bf16x8 ah[2], al[2];
+        int pb = pbase0;
+        asm volatile("" : "+v"(pb));       // opaque: otherwise hipcc computes the 18 (tap, M tile) fragment addresses ahead of the loop and keeps them live (spills at NJ = 8)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int p = pbase0 + i * PP + off;
+            const int p = pb + i * PP + off;
             const int ih = p * 8 + (kg ^ (p & 7));
             ah[i] = *reinterpret_cast<const bf16x8*>(&sP[ih]);
             al[i] = *reinterpret_cast<const bf16x8*>(&sP[ih ^ 4]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
             const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
 #pragma unroll
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
                     al[i] = *reinterpret_cast<const bf16x8*>(&sA[ih ^ 4]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
                     const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
 #pragma unroll
@@ -400,12 +416,14 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     const int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     auto run = [&](auto epic) __attribute__((always_inline)) {
         constexpr int EPI = decltype(epic)::value;
-        PAux cur = patch_prefetch<EPI>(a, img, yb, x0, 0, le);
+        const int cb = nb * BN;                                // first output channel of this workgroup
+        PAux cur = patch_prefetch<EPI>(a, img, yb, x0, cb, le);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NJ / 2; ++ni) {
             PAux nxt = cur;
-            if (ni == 0) nxt = patch_prefetch<EPI>(a, img, yb, x0, 32, le);
-            patch_block_out<EPI>(a, acc[0][2 * ni], acc[0][2 * ni + 1], acc[1][2 * ni], acc[1][2 * ni + 1], img, yb, x0, ni * 32, patch, le, cur);
+            if (ni + 1 < NJ / 2 && cb + (ni + 1) * 32 < a.cout) nxt = patch_prefetch<EPI>(a, img, yb, x0, cb + (ni + 1) * 32, le);
+            if (cb + ni * 32 < a.cout)                         // (cout % 32 == 0: blocks are all-in or all-out)
+                patch_block_out<EPI>(a, acc[0][2 * ni], acc[0][2 * ni + 1], acc[1][2 * ni], acc[1][2 * ni + 1], img, yb, x0, cb + ni * 32, patch, le, cur);
             cur = nxt;
         }
     };
@@ -421,15 +439,19 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
 int vh_diag_conv_patch() { return VH_DIAG_FLAG; }
 
-// Launch of the patch-resident kernel (arguments validated by vh_conv / chosen by vh_conv_x3_glds_dispatch): 3x3, no `up`, cout == 64,
-// epilogue STORE / SCALE_SILU / MPSUM without res_up.  One workgroup per 16x16 output tile per image.
+// Launch of the patch-resident kernel (arguments validated by vh_conv / chosen by vh_conv_x3_glds_dispatch): 3x3, no `up`, cout % 32 == 0,
+// epilogue STORE / SCALE_SILU / MPSUM without res_up.  One workgroup per 16x16 output tile per image and block of 64 (with a tail segment)
+// or 128 output channels.
 void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
     k.ptx = (k.w + PT - 1) / PT;
     k.pty = (k.h + PT - 1) / PT;
     k.div_ptx = vhconv::fastdiv_make((unsigned)k.ptx);
     k.div_ptiles = vhconv::fastdiv_make((unsigned)(k.ptx * k.pty));
-    const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty);
+    const bool wide = k.cout > 64 && k.c1 == 0;                // 128 output channels per workgroup (no tail instantiation: see the kernel)
+    k.NT = (k.cout + (wide ? 127 : 63)) / (wide ? 128 : 64);
+    const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty * k.NT);
     const bool pf = k.cin_pad <= 64;
-    if (k.c1 > 0) { if (pf) hipLaunchKernelGGL((conv_x3_patch<true, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<true, false>), dim3(grid), dim3(512), 0, s, k); }
-    else { if (pf) hipLaunchKernelGGL((conv_x3_patch<false, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<false, false>), dim3(grid), dim3(512), 0, s, k); }
+    if (wide) hipLaunchKernelGGL((conv_x3_patch<8, false, false>), dim3(grid), dim3(512), 0, s, k);
+    else if (k.c1 > 0) { if (pf) hipLaunchKernelGGL((conv_x3_patch<4, true, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<4, true, false>), dim3(grid), dim3(512), 0, s, k); }
+    else { if (pf) hipLaunchKernelGGL((conv_x3_patch<4, false, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<4, false, false>), dim3(grid), dim3(512), 0, s, k); }
 }
