@@ -37,7 +37,7 @@ extern "C" {
 typedef struct vh_ctx vh_ctx;
 typedef struct vh_plan vh_plan;
 
-#define VH_ABI_VERSION 3
+#define VH_ABI_VERSION 4
 int vh_abi_version(void);                                /* == VH_ABI_VERSION of the header the library was built from */
 const char* vh_last_error(void);
 
@@ -59,6 +59,8 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * "conv_korder_mb": input size in MB above which 3x3 convolutions take the chunk-major K order (default: see conv_x3.hip);
  * "conv_ksplit": > 0 forces that many K slices where split-K is possible (default 0: the dispatcher's rule);
  * "conv_patch": -1 (default) eligible 3x3 Cout == 64 layers take the patch-resident kernel by the size rule, 0 never, 1 whenever eligible;
+ * "fuse_concat": whole-network walks (vh_net_*, and vivid_amd.engine through the same knob): the halves of a decoder block's concat input written by
+ *   the convolutions that produce them (vh_s8_sink) - 2 both halves, 1 the x half only, 0 (default) never (a vh_split pass over the fp32 tensors);
  * "conv_patch_delay": start delay, in units of 2048 shader cycles, of every CU's second workgroup in the first round of a patch-kernel launch.
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);
@@ -140,6 +142,16 @@ enum { VH_EPI_STORE = 0, VH_EPI_SCALE_SILU = 1, VH_EPI_MPSUM = 2, VH_EPI_QKV = 3
  * ordered [head][j][d] (o' = (head*nj + j)*D + d) instead of the reference's (head*D + d)*nj + j, so that a 64- (D = 64) or
  * 32-column (D = 32) accumulator slab is one (head, j): permute the rows of w before vh_prep_weight.
  * Requires D = cout / (heads*nj) == 64 or 32, s % 32 == 0, koff % 16 == 0, out == NULL. */
+/* Extra S8 outputs of a convolution (patch-resident kernel only, see `tile`): the result, scaled and optionally passed through mp_silu, written
+ * straight into a channel range of a wider S8 tensor - the half of a decoder block's `mp_silu(mp_cat(x, skip))` input (training/models.py:78-84,
+ * :174, :403) that this convolution produces, in the form (and with the bits) vh_split would write from the fp32 result:
+ *   sink[pixel][c_off + o] = split( silu ? mp_silu(scale * y[pixel][o]) : scale * y[pixel][o] ),   rows of c_total channels. */
+typedef struct {
+    void* ptr;             /* NULL: unused */
+    int c_total, c_off;    /* channels per pixel of the destination tensor (multiple of 32); first channel written (multiple of 32) */
+    float scale;           /* the mp_cat weight of this half */
+    int silu;              /* 1: mp_silu after scaling (conv_res0's input), 0: raw (conv_skip's input) */
+} vh_s8_sink;
 typedef struct {
     float* q; void* k; void* v;            /* as vh_qkv_split_args (q unused for nj == 2) */
     int heads, nj, rows_per_b, koff, kl;   /* s = h*w of the convolution; rows = its rows */
@@ -191,11 +203,17 @@ typedef struct {
                                               workgroup per 16x16-pixel output tile of one image, its (16+2)^2-pixel input patch staged once per
                                               32-channel chunk and read in place by the nine taps; chunk-major K order (sums agree with the other
                                               tiles to fp32 rounding). */
+    vh_s8_sink sink[2];                    /* optional extra S8 outputs (see vh_s8_sink); only a launch that takes the patch-resident kernel writes them
+                                              (vh_conv_takes_patch() == 1 or tile == VH_TILE_PATCH16), any other is refused.  With a sink, `out` and
+                                              `out_s8` may both be NULL. */
 } vh_conv_args;
 enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
 enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5, VH_TILE_256x192 = 7,
        VH_TILE_PATCH16 = 8 };
 int vh_conv(vh_ctx* ctx, const vh_conv_args* a);
+/* 1 if vh_conv would run these arguments on the patch-resident kernel (eligible and chosen by the size rule / tile / knob), 0 if not,
+ * negative on invalid arguments: lets a host decide whether it may attach sinks. */
+int vh_conv_takes_patch(const vh_conv_args* a);
 
 /* ---- K6 (+K9): pixel norm with optional 2x2 mean pooling ------------------
  * normalize(x, dim=1) :37-42 applied after resample 'down' (:58-59, a 2x2 mean):
@@ -223,6 +241,9 @@ typedef struct {
     long long npix; int c_pad;
     void* out;
     void* out_raw;                         /* optional second S8 output without the prologue (conv_skip's input) */
+    int out_c_total, out_c_off;            /* 0, 0: the outputs are dense [npix][c_pad].  Otherwise they are rows of out_c_total channels and the
+                                              c_pad channels produced here start at channel out_c_off (multiples of 32): the other channels of the
+                                              row are written by someone else (a convolution's vh_s8_sink) */
 } vh_split_args;
 int vh_split(vh_ctx* ctx, const vh_split_args* a);
 

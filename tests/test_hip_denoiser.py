@@ -270,3 +270,48 @@ def test_non_power_of_two_resolution_vs_oracle(precision):
         assert got.shape == want.shape == (3, 3, 24, 24)
         assert rel_l2(got.cpu(), want) < TOL_D[precision], (precision, sigma)
         assert rel_l2(got_lv.cpu(), want_lv) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["tiny_dual", "tiny_sr", "sr256"])
+def test_concat_fusion_modes_change_nothing(name):
+    """Knob "fuse_concat" (VIVID_FUSE_CONCAT): the halves of a decoder block's mp_silu(mp_cat(x, skip)) input written by the convolutions
+    that produce x / skip (vh_s8_sink) instead of by a vh_split pass - the same bits either way, so the network output must be EQUAL in all
+    three modes (0 never, 1 the x half, 2 both), in the Python engine and in the C-level walk, which read the same knob."""
+    import vivid_amd
+    from vivid_amd import _lib
+    from vivid_amd.cnet import CNet
+    if name == "sr256":                 # the reference's SR stage at full size: the smallest preset whose launches take the patch kernel (>= 256 tiles)
+        cfg, seed = vivid_amd.vivid_sr(256, noisy_sr=0.0), 2
+        g = torch.Generator().manual_seed(5)
+        inp = dict(src=torch.rand(2, 3, 256, 256, generator=g) * 2 - 1, geometry=torch.randn(2, 20, generator=g),
+                   cond=torch.rand(1, 3, 256, 256, generator=g) * 2 - 1)
+        x = torch.randn(2, 3, 256, 256, generator=g) * 2
+    else:
+        case = CASES[name]
+        cfg, seed = case["cfg"], case["seed"]
+        inp = make_inputs(case)
+        x = x_for(inp, 1.7)
+    sd = vivid_amd.synth_state_dict(cfg, seed=seed)
+    rows = inp["src"].shape[0]
+    sig = torch.full((rows,), 1.7)
+    outs = []
+    try:
+        for mode in (0, 1, 2):
+            os.environ["VIVID_FUSE_CONCAT"] = str(mode)
+            net = vivid_amd.NVPrecond.from_config(cfg, precision="bf16x3")
+            net.load_state_dict(sd, strict=True)
+            net.noisy_sr = 0.0
+            net = net.cuda()
+            a = net(inp["src"].cuda(), x.cuda(), sig.cuda(), inp["geometry"].cuda(), inp["cond"].cuda() if "cond" in inp else None)
+            cn = CNet(cfg)
+            cn.load_state_dict(sd)
+            b = cn(inp["src"].cuda(), x.cuda(), sig.cuda(), inp["geometry"].cuda(), inp["cond"].cuda() if "cond" in inp else None)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), mode
+            outs.append(a)
+            if mode == 2 and name == "sr256":
+                assert any("sinks=" in d for d in list(net._engine.programs.values())[0].oplog), "no convolution carried a sink"
+    finally:
+        os.environ.pop("VIVID_FUSE_CONCAT", None)
+        _lib.set_knob("fuse_concat", 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -245,6 +245,73 @@ def test_conv_patch_kernel_shapes(ctx, rows, h, w, cin, epi):
         assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5, tile
 
 
+@pytest.mark.parametrize("cout,c1,epi", [(64, 0, 2), (64, 64, 0), (128, 0, 0), (128, 0, 2), (256, 0, 1)])
+def test_conv_s8_sinks_equal_split_of_the_result(ctx, cout, c1, epi):
+    """vh_s8_sink: a convolution on the patch-resident kernel writes the scaled / mp_silu'd S8 forms of its result straight into a channel range
+    of a wider tensor - the x or skip half of a decoder block's mp_silu(mp_cat(x, skip)) input (training/models.py:78-84, :174).  Must be the
+    BITS vh_split derives from the fp32 result (the engine mixes the two freely: one half by sink, the other by a half-range vh_split), with
+    and without the fp32 output, for 64- and 128-channel blocks, two N blocks, a tail segment; the rest of the wide rows stays untouched."""
+    from vivid_amd import _lib as L
+    rows, h, w, cin = 2, 40, 24, 64
+    g = torch.Generator().manual_seed(cout + c1 + epi)
+    M = rows * h * w
+    x = torch.randn(M, cin, generator=g).cuda()
+    wgt = torch.randn(cout, cin, 3, 3, generator=g).cuda()
+    xs8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=x.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin, out=xs8.data_ptr(), out_raw=None))
+    k_pad = 9 * cin + c1
+    wt = torch.zeros(k_pad // 4 * cout * 4, device="cuda")
+    ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=9, cin_pad=cin, k_pad=9 * cin, gain_ptr=None, gain_value=1.0,
+                                                wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2, k_off=0, k_stride=k_pad if c1 else 0))
+    x1s8 = None
+    if c1:
+        x1 = torch.randn(M, c1, generator=g).cuda()
+        w1 = torch.randn(cout, c1, 1, 1, generator=g).cuda()
+        x1s8 = torch.empty(M * c1, device="cuda")
+        ctx.call("vh_split", L.SplitArgs(src0=x1.data_ptr(), src1=None, c0=c1, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=c1, out=x1s8.data_ptr(), out_raw=None))
+        ctx.call("vh_prep_weight", L.PrepWeightArgs(w=w1.data_ptr(), cout=cout, cin=c1, taps=1, cin_pad=c1, k_pad=c1, gain_ptr=None, gain_value=1.0,
+                                                    wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2, k_off=9 * cin, k_stride=k_pad))
+    res = torch.randn(M, cout, generator=g).cuda()
+    cvec = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda()
+    Ct, off, scale = cout + 96, 32, 0.83
+
+    def args(out, sinks):
+        a = L.ConvArgs(src0=xs8.data_ptr(), src1=x1s8.data_ptr() if c1 else None, c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0,
+                       wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0, cout=cout,
+                       out=out.data_ptr() if out is not None else None, out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=epi,
+                       cvec=cvec.data_ptr() if epi == 1 else None, cvec_ld=cout if epi == 1 else 0, res=res.data_ptr() if epi == 2 else None, res_up=0,
+                       ta=0.7, tb=0.3, clip=1.5 if epi != 1 else 0.0, tile=8)
+        for i, (buf, silu) in enumerate(sinks):
+            a.sink[i] = L.S8Sink(ptr=buf.data_ptr(), c_total=Ct, c_off=off, scale=scale, silu=silu)
+        return a
+
+    assert L.lib().vh_conv_takes_patch(ctypes.byref(args(torch.empty(1, device="cuda"), []))) == 1
+    y = torch.empty(M, cout, device="cuda")
+    ctx.call("vh_conv", args(y, []))
+    # what vh_split makes of the fp32 result, into the same channel range of wide rows
+    want = [torch.full((M * Ct,), 7.0, device="cuda") for _ in range(2)]
+    ctx.call("vh_split", L.SplitArgs(src0=y.data_ptr(), src1=None, c0=cout, c1=0, scale0=scale, scale1=1.0, pro=1, npix=M, c_pad=cout,
+                                     out=want[0].data_ptr(), out_raw=want[1].data_ptr(), out_c_total=Ct, out_c_off=off))
+    for with_fp32 in (True, False):
+        got = [torch.full((M * Ct,), 7.0, device="cuda") for _ in range(2)]
+        y2 = torch.empty(M, cout, device="cuda") if with_fp32 else None
+        ctx.call("vh_conv", args(y2, [(got[0], 1), (got[1], 0)]))
+        torch.cuda.synchronize()
+        assert torch.equal(got[0].view(torch.int32), want[0].view(torch.int32)) and torch.equal(got[1].view(torch.int32), want[1].view(torch.int32))
+        if with_fp32:
+            assert torch.equal(y2, y)
+    # untouched outside [off, off + cout), written inside
+    wide = want[0].view(M, Ct)
+    assert bool((wide[:, :off] == 7.0).all()) and bool((wide[:, off + cout:] == 7.0).all()) and not bool((wide[:, off:off + cout] == 7.0).all())
+    dec = _s8_decode(want[1].view(M, Ct)[:, off:off + cout].contiguous().view(-1), (M, cout))
+    assert rel_l2(dec.cpu(), (y * scale).cpu()) < 1e-5          # (hi + lo carries 16 mantissa bits)
+    # a launch that does not take the patch kernel refuses sinks
+    a = args(y, [(got[0], 1)])
+    a.tile = 5 if cout == 64 else 1
+    with pytest.raises(L.VividHipError, match="sink"):
+        ctx.call("vh_conv", a)
+
+
 @pytest.mark.parametrize("korder", [1, 2])
 @pytest.mark.parametrize("tile,cout,c1,scratch", [(0, 96, 160, True), (0, 384, 768, True), (1, 128, 256, False), (2, 256, 96, False), (3, 128, 64, False),
                                                   (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False), (7, 192, 384, False), (7, 96, 64, False),

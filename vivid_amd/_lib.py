@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIVID_HIP_LIB") or os.path.join(_HERE, "libvivid_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
-ABI_VERSION = 3          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
+ABI_VERSION = 4          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
 
 
 class VividHipError(RuntimeError):
@@ -33,6 +33,11 @@ class QkvEpilogue(C.Structure):
                 ("rows_per_b", C.c_int), ("koff", C.c_int), ("kl", C.c_int), ("qscale", C.c_float)]
 
 
+class S8Sink(C.Structure):
+    """vh_s8_sink"""
+    _fields_ = [("ptr", C.c_void_p), ("c_total", C.c_int), ("c_off", C.c_int), ("scale", C.c_float), ("silu", C.c_int)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
                 ("scale0", C.c_float), ("scale1", C.c_float),
@@ -43,7 +48,7 @@ class ConvArgs(C.Structure):
                 ("prec", C.c_int), ("kernel", C.c_int), ("epi", C.c_int),
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int), ("res_scale", C.c_void_p),
                 ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p), ("stagger", C.c_int),
-                ("korder", C.c_int), ("tile", C.c_int)]
+                ("korder", C.c_int), ("tile", C.c_int), ("sink", S8Sink * 2)]
 
 
 class PixnormArgs(C.Structure):
@@ -54,7 +59,7 @@ class PixnormArgs(C.Structure):
 class SplitArgs(C.Structure):
     _fields_ = [("src0", C.c_void_p), ("src1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
                 ("scale0", C.c_float), ("scale1", C.c_float), ("pro", C.c_int), ("npix", C.c_longlong),
-                ("c_pad", C.c_int), ("out", C.c_void_p), ("out_raw", C.c_void_p)]
+                ("c_pad", C.c_int), ("out", C.c_void_p), ("out_raw", C.c_void_p), ("out_c_total", C.c_int), ("out_c_off", C.c_int)]
 
 
 class QkvSplitArgs(C.Structure):
@@ -171,7 +176,7 @@ OPS = {
     "vh_nonzero_flag": NonzeroArgs, "vh_resample": ResampleArgs, "vh_moments": MomentsArgs, "vh_psnr_sum": PsnrArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
-CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob",
+CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob", "vh_conv_takes_patch",
            "vh_profile_enable", "vh_profile_read", "vh_profile_read_list",
            "vh_plan_begin", "vh_plan_end", "vh_plan_abort", "vh_plan_capture_graph", "vh_plan_run", "vh_plan_num_ops", "vh_plan_destroy"]
 
@@ -221,6 +226,8 @@ def lib():
         fn.restype = C.c_int
     for name in CONTROL:
         getattr(L, name)
+    L.vh_conv_takes_patch.argtypes = [C.POINTER(ConvArgs)]
+    L.vh_conv_takes_patch.restype = C.c_int
     L.vh_net_create.argtypes = [C.c_void_p, C.POINTER(NetConfigC), C.POINTER(C.c_void_p)]
     L.vh_net_destroy.argtypes = [C.c_void_p]
     L.vh_net_num_params.argtypes = [C.c_void_p]

@@ -229,12 +229,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm(const ConvK a) {
 }  // namespace
 
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, vhconv::ConvK k, double flops, double bytes);
+int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs);      // conv_x3.hip: 1 = the patch-resident kernel runs these arguments
+
+extern "C" int vh_conv_takes_patch(const vh_conv_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_conv_takes_patch: null args");
+    if (p->prec != VH_PREC_BF16X3 || p->kernel != VH_CONV_GLDS256 || p->rows <= 0 || p->h <= 0 || p->w <= 0 || p->cout <= 0) return 0;
+    long long pwgs = 0;
+    return vh_conv_patch_choice(*p, (long long)p->rows * p->h * p->w, &pwgs) == 1 ? 1 : 0;
+}
 
 extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_conv: null args");
     const vh_conv_args a = *p;
     VH_REQUIRE(a.taps == 1 || a.taps == 9, "vh_conv: taps must be 1 or 9 (got %d)", a.taps);
-    VH_REQUIRE(a.src0 && a.wt && (a.out || a.out_s8 || a.epi == VH_EPI_QKV), "vh_conv: null tensor");
+    const bool has_sink = a.sink[0].ptr || a.sink[1].ptr;
+    VH_REQUIRE(a.src0 && a.wt && (a.out || a.out_s8 || a.epi == VH_EPI_QKV || has_sink), "vh_conv: null tensor");
+    for (int i = 0; i < 2; ++i)
+        VH_REQUIRE(!a.sink[i].ptr || (a.sink[i].c_total % 32 == 0 && a.sink[i].c_off % 32 == 0 && a.sink[i].c_off >= 0 && a.sink[i].c_off + a.cout <= a.sink[i].c_total &&
+                                      a.cout % 32 == 0 && vh_aligned16(a.sink[i].ptr)),
+                   "vh_conv: sink %d: c_total / c_off must be multiples of 32 with c_off + cout <= c_total (cout %% 32 == 0), 16-byte aligned", i);
     VH_REQUIRE(a.prec == VH_PREC_F32 || a.prec == VH_PREC_BF16X3, "vh_conv: bad prec %d", a.prec);
     // bf16x3 + VH_CONV_GLDS256 + 3x3: a second S8 source is a 1-TAP TAIL SEGMENT of the K loop (see vh_conv_args.src1), not a channel concat
     const bool tail = a.prec == VH_PREC_BF16X3 && a.src1 != nullptr;
@@ -291,6 +304,11 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.div_hw = fastdiv_make((unsigned)(a.h * a.w)); k.div_w = fastdiv_make((unsigned)a.w); k.div_c0u = fastdiv_make((unsigned)(a.c0 / 4));
     k.ksplit = 1; k.scratch = nullptr; k.korder = 0; k.stagger = 0; k.dbg = nullptr;
     k.ptx = k.pty = 0; k.div_ptx = k.div_ptiles = fastdiv_make(1);
+    for (int i = 0; i < 2; ++i) {
+        k.sk_ptr[i] = static_cast<unsigned short*>(a.sink[i].ptr); k.sk_ct[i] = a.sink[i].c_total; k.sk_off[i] = a.sink[i].c_off;
+        k.sk_scale[i] = a.sink[i].scale; k.sk_silu[i] = a.sink[i].silu;
+    }
+    VH_REQUIRE(!has_sink || a.kernel == VH_CONV_GLDS256, "vh_conv: S8 sinks are written by the patch-resident kernel (VH_CONV_GLDS256) only");
     k.q = nullptr; k.qk = k.qv = nullptr; k.q_heads = k.q_nj = k.q_rows_per_b = k.q_koff = k.q_klp = 0; k.q_d = 64; k.q_scale = 1.f;
     if (a.epi == VH_EPI_QKV) {
         const vh_qkv_epilogue& e = *a.qkv;

@@ -114,20 +114,34 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
         }
         const int yy = yb + (i >> 1), xx = x0 + rsub + 8 * (i & 1);
         const bool ok = yy < a.h && xx < a.w;                  // (ragged image edges: the tile hangs over)
-        const size_t eo = (((size_t)img * a.h + yy) * a.w + xx) * a.cout + c0 + 4 * cg;
+        const size_t gm = ((size_t)img * a.h + yy) * a.w + xx;
+        const size_t eo = gm * a.cout + c0 + 4 * cg;
         if (a.out && ok) *reinterpret_cast<float4*>(a.out + eo) = make_float4(y[0], y[1], y[2], y[3]);
-        if (a.out_s8) {
-            // the lane pair (even, odd) holds the two halves of one 8-channel chunk [hi x8 | lo x8]: swap one 8-byte piece so that the even
-            // lane writes the whole hi half and the odd lane the whole lo half - one 16-byte store each (conv_common.h s8_store_half_chunk)
+        // S8 store of the lane's 4 channels = half of one 8-channel chunk [hi x8 | lo x8]: the lane pair (even, odd) swaps one 8-byte piece so that
+        // the even lane writes the whole hi half and the odd lane the whole lo half - one 16-byte store each (conv_common.h s8_store_half_chunk)
+        auto s8_pair_store = [&](unsigned short* chunk, const float (&v)[4]) __attribute__((always_inline)) {
             unsigned h[4], lo[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                h[j] = bf16_rn_bits(y[j]);
-                lo[j] = bf16_rn_bits(y[j] - __uint_as_float(h[j] << 16));
+                h[j] = bf16_rn_bits(v[j]);
+                lo[j] = bf16_rn_bits(v[j] - __uint_as_float(h[j] << 16));
             }
             const unsigned H0 = h[0] | (h[1] << 16), H1 = h[2] | (h[3] << 16), L0 = lo[0] | (lo[1] << 16), L1 = lo[2] | (lo[3] << 16);
             const unsigned r0 = __shfl_xor(odd ? H0 : L0, 1), r1 = __shfl_xor(odd ? H1 : L1, 1);
-            if (ok) *reinterpret_cast<uint4*>(a.out_s8 + (eo - sub) * 2 + (odd ? 8 : 0)) = odd ? make_uint4(r0, r1, L0, L1) : make_uint4(H0, H1, r0, r1);
+            if (ok) *reinterpret_cast<uint4*>(chunk + (odd ? 8 : 0)) = odd ? make_uint4(r0, r1, L0, L1) : make_uint4(H0, H1, r0, r1);
+        };
+        if (a.out_s8) s8_pair_store(a.out_s8 + (eo - sub) * 2, y);
+        // sinks (vh_s8_sink): the same values as vh_split would derive from the fp32 result - scale, mp_silu, hi/lo split - into a channel range of a wider tensor
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!a.sk_ptr[k]) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = y[j] * a.sk_scale[k];
+                if (a.sk_silu[k]) v[j] = mp_silu_dev(v[j]);
+            }
+            s8_pair_store(a.sk_ptr[k] + (gm * a.sk_ct[k] + (size_t)(a.sk_off[k] + c0 + 4 * cg - sub)) * 2, v);
         }
     }
 }
@@ -417,14 +431,25 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     auto run = [&](auto epic) __attribute__((always_inline)) {
         constexpr int EPI = decltype(epic)::value;
         const int cb = nb * BN;                                // first output channel of this workgroup
-        PAux cur = patch_prefetch<EPI>(a, img, yb, x0, cb, le);
+        if constexpr (NJ == 4) {
+            // the residual / cvec values of block 1 are requested before block 0 is written out
+            PAux cur = patch_prefetch<EPI>(a, img, yb, x0, cb, le);
 #pragma unroll
-        for (int ni = 0; ni < NJ / 2; ++ni) {
-            PAux nxt = cur;
-            if (ni + 1 < NJ / 2 && cb + (ni + 1) * 32 < a.cout) nxt = patch_prefetch<EPI>(a, img, yb, x0, cb + (ni + 1) * 32, le);
-            if (cb + ni * 32 < a.cout)                         // (cout % 32 == 0: blocks are all-in or all-out)
+            for (int ni = 0; ni < NJ / 2; ++ni) {
+                PAux nxt = cur;
+                if (ni + 1 < NJ / 2 && cb + (ni + 1) * 32 < a.cout) nxt = patch_prefetch<EPI>(a, img, yb, x0, cb + (ni + 1) * 32, le);
+                if (cb + ni * 32 < a.cout)                     // (cout % 32 == 0: blocks are all-in or all-out)
+                    patch_block_out<EPI>(a, acc[0][2 * ni], acc[0][2 * ni + 1], acc[1][2 * ni], acc[1][2 * ni + 1], img, yb, x0, cb + ni * 32, patch, le, cur);
+                cur = nxt;
+            }
+        } else {
+            // (64 accumulator registers: no room to hold a second block's values in flight - 24 B of scratch with them)
+#pragma unroll
+            for (int ni = 0; ni < NJ / 2; ++ni) {
+                if (cb + ni * 32 >= a.cout) continue;
+                const PAux cur = patch_prefetch<EPI>(a, img, yb, x0, cb + ni * 32, le);
                 patch_block_out<EPI>(a, acc[0][2 * ni], acc[0][2 * ni + 1], acc[1][2 * ni], acc[1][2 * ni + 1], img, yb, x0, cb + ni * 32, patch, le, cur);
-            cur = nxt;
+            }
         }
     };
     if (a.epi == VH_EPI_MPSUM) run(std::integral_constant<int, VH_EPI_MPSUM>{});

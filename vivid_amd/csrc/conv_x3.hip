@@ -630,29 +630,38 @@ int vh_diag_conv1() { return VH_DIAG_FLAG; }
 #if VH_CONV_TU != 1
 int vh_diag_conv3() { return VH_DIAG_FLAG; }
 void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s);      // conv_patch.hip
+// Patch-resident kernel (conv_patch.hip): does it run these (validated) arguments?  1 yes, 0 no, -1 = VH_TILE_PATCH16 forced on ineligible ones.
+int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out) {
+    // (the kernel addresses its inputs through 32-bit offsets in 16-byte units: M * c / 4 < 2^32)
+    const bool patch_ok = a.taps == 9 && !a.up && a.cout % 32 == 0 && a.epi != VH_EPI_QKV && !(a.epi == VH_EPI_MPSUM && a.res_up) &&
+                          a.prec == VH_PREC_BF16X3 && a.kernel == VH_CONV_GLDS256 &&
+                          (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0;
+    if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
+    const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
+    const bool tailp = a.src1 != nullptr;
+    const long long pwgs = ptiles * ((a.cout > 64 && !tailp) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
+    if (pwgs_out) *pwgs_out = pwgs;
+    const int pknob = vh_knob(VH_KNOB_CONV_PATCH);
+    // Size rule, from same-device A/B against the tile the rules of vh_conv_x3_glds_dispatch pick (profiles/r04_ab_conv_patch_vs_glds.txt): the patch
+    // kernel leads by +20..29 % at Cout = 64, +13..20 % at Cout = 128 (256^2 / 512^2 / 1024^2), +3..10 % at Cout = 256 / 384 down to 64^2, ties at
+    // 32^2 x 512 and loses where its 16x16-pixel tiles do not fit the image (16^2: 0.6-0.87x, 8^2: 0.38x), on small grids (no split-K: 0.35-0.67x at
+    // 32 tiles), at Cout = 192 (two blocks of 128 channels, the second half empty: 0.93-0.96x against the 256x192 tile) and with a tail segment at
+    // Cout >= 256 (64-channel blocks with the tail's 80 KB of LDS: 0.93-0.99x).
+    const int mres = a.h < a.w ? a.h : a.w;
+    const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0) && (!tailp || a.cout <= 128) && (mres >= 64 || a.cout <= 256);
+    return (patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))))) ? 1 : 0;
+}
+
 // Entry used by vh_conv for prec == VH_PREC_BF16X3 && kernel == VH_CONV_GLDS (arguments already validated).
 int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double flops, double bytes) {
     const long long M = k.M;
     {
-        // Patch-resident kernel (conv_patch.hip) for the 3x3 Cout == 64 layers: one workgroup per 16x16-pixel tile per image.
-        // (the kernel addresses its input through 32-bit offsets in 16-byte units: M * c0 / 4 < 2^32)
-        const bool patch_ok = a.taps == 9 && !a.up && a.cout % 32 == 0 && a.epi != VH_EPI_QKV && !(a.epi == VH_EPI_MPSUM && a.res_up) &&
-                              (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0;
-        if (a.tile == VH_TILE_PATCH16 && !patch_ok)
-            return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up` / res_up, cout %% 32 == 0 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
-        const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
-        const bool tailp = a.src1 != nullptr;
-        const long long pwgs = ptiles * ((a.cout > 64 && !tailp) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
-        const int pknob = vh_knob(VH_KNOB_CONV_PATCH);
-        // Size rule, from same-device A/B against the tile the rules below pick (profiles/r04_ab_conv_patch_vs_glds.txt): the patch kernel leads by
-        // +20..29 % at Cout = 64, +13..20 % at Cout = 128 (256^2 / 512^2 / 1024^2), +3..10 % at Cout = 256 / 384 down to 64^2, ties at 32^2 x 512 and
-        // loses where its 16x16-pixel tiles do not fit the image (16^2: 0.6-0.87x, 8^2: 0.38x), on small grids (no split-K: 0.35-0.67x at 32 tiles),
-        // at Cout = 192 (two blocks of 128 channels, the second half empty: 0.93-0.96x against the 256x192 tile) and with a tail segment at
-        // Cout >= 256 (64-channel blocks with the tail's 80 KB of LDS: 0.93-0.99x).
-        const int mres = a.h < a.w ? a.h : a.w;
-        const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0) && (!tailp || a.cout <= 128) && (mres >= 64 || a.cout <= 256);
-        const bool patch = patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))));
-        if (patch) {
+        long long pwgs = 0;
+        const int pc = vh_conv_patch_choice(a, M, &pwgs);
+        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up` / res_up, cout %% 32 == 0 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
+        if ((a.sink[0].ptr || a.sink[1].ptr) && pc != 1)
+            return vh_fail(VH_EINVAL, "vh_conv: S8 sinks given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
+        if (pc == 1) {
             if (pwgs >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
             k.ksplit = 1; k.scratch = nullptr; k.korder = 1; k.stagger = vh_knob(VH_KNOB_CONV_PATCH_DELAY); k.dbg = vh_debug_ptr();
             return vh_dispatch(ctx, VH_TAG_CONV3, flops, bytes, [k](hipStream_t s) -> int {

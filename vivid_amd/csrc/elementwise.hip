@@ -260,13 +260,15 @@ __global__ __launch_bounds__(256) void split_k(vh_split_args a, long long total,
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= sc;
-    if (a.out_raw) store_s8_chunk(reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out_raw) + (size_t)i * 16), v);
+    // output chunk index: dense, or inside rows of out_c_total channels from channel out_c_off on
+    const size_t oi = a.out_c_total ? (size_t)pix * (size_t)(a.out_c_total >> 3) + (size_t)((a.out_c_off + c) >> 3) : (size_t)i;
+    if (a.out_raw) store_s8_chunk(reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out_raw) + oi * 16), v);
     if (!a.out) return;
     if (a.pro == VH_PRO_SILU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = mp_silu_dev(v[j]);
     }
-    store_s8_chunk(reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out) + (size_t)i * 16), v);
+    store_s8_chunk(reinterpret_cast<uint4*>(static_cast<unsigned short*>(a.out) + oi * 16), v);
 }
 
 // ---------------------------------------------------------------- q/k/v split + head norm
@@ -606,6 +608,8 @@ extern "C" int vh_split(vh_ctx* ctx, const vh_split_args* p) {
     VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 8 == 0) : a.c1 == 0, "vh_split: bad c1 %d", a.c1);
     VH_REQUIRE(a.c_pad % 32 == 0 && a.c_pad >= a.c0 + a.c1, "vh_split: c_pad %d must be a multiple of 32 >= %d", a.c_pad, a.c0 + a.c1);
     VH_REQUIRE(a.npix > 0 && (a.pro == VH_PRO_NONE || a.pro == VH_PRO_SILU), "vh_split: bad arguments");
+    VH_REQUIRE((a.out_c_total == 0 && a.out_c_off == 0) || (a.out_c_total % 32 == 0 && a.out_c_off % 32 == 0 && a.out_c_off >= 0 && a.out_c_off + a.c_pad <= a.out_c_total),
+               "vh_split: out_c_total / out_c_off must be multiples of 32 with out_c_off + c_pad <= out_c_total (got %d, %d, c_pad %d)", a.out_c_total, a.out_c_off, a.c_pad);
     VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.out) && vh_aligned16(a.out_raw), "vh_split: pointers must be 16-byte aligned");
     const long long total = a.npix * (a.c_pad / 8);
     return vh_dispatch(ctx, VH_TAG_SPLIT, 0.0, 4.0 * (double)a.npix * ((double)a.c0 + a.c1 + a.c_pad * ((a.out ? 1 : 0) + (a.out_raw ? 1 : 0))), [a, total](hipStream_t s) -> int {

@@ -154,6 +154,8 @@ struct Buf { long long off = -1; long long n = 0; int c = 0; float* abs = nullpt
 struct Weight { float* wt = nullptr; size_t off = 0; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0, nj = 0, D = 0, fused_c1 = 0; const float* gain = nullptr; bool has_gain = false; };
 
 struct FeatBuf { Buf f32, s8; };
+// one decoder block's concat input mp_silu(mp_cat(x, skip)) (training/models.py:78-84, :174) whose halves are written by their producers (vh_s8_sink)
+struct CatState { int rows = 0, R = 0, Na = 0, Nb = 0; float sc0 = 1.f, sc1 = 1.f; bool raw = false, ok = false, x_done = false, skip_done = false; Buf cs, craw; };
 struct Program {
     int B = 0, mode = 0;
     vh_plan* plan = nullptr;
@@ -183,6 +185,7 @@ struct vh_net {
     std::map<std::tuple<int, int, int>, std::unique_ptr<Program>> programs;      // (mode, slot, batch)
     // walk state
     Arena* A = nullptr; float* base = nullptr; bool emit = false; int rc = VH_OK;
+    std::map<int, CatState> cat;          // by decoder block index, for the network being walked
 };
 
 namespace {
@@ -209,13 +212,35 @@ struct ConvOpt {
     float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr; bool s8_only = false, also_s8 = false; const vh_qkv_epilogue* qkv = nullptr;
     const Buf* src1 = nullptr;        // S8 second source: the 1-tap tail segment of a fused conv_res1 + conv_skip
     const Buf* res_scale = nullptr;   // per-pixel factor of the residual
+    int sink_j = -1, sink_half = 0;   // this result is half 0 (x) / 1 (skip) of decoder block sink_j's concat input: written as S8 by this launch if it takes the patch kernel
+    bool fp32_optional = false;       // ... and nothing else reads its fp32 form
 };
+Buf ghost(int c) { Buf b; b.c = c; return b; }       // a tensor that was never materialised in fp32 (off < 0): only its channel count is known
 // bf16x3 glds convolution of an S8 source; returns (fp32 out, S8 out) - either may be empty
 std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, int h, int w, ConvOpt o) {
     Buf out, out8;
     if (o.qkv) o.epi = VH_EPI_QKV;
+    vh_s8_sink sinks[2] = {};
+    bool sunk = false;
+    if (o.sink_j >= 0 && !o.qkv) {
+        vh_conv_args q{};
+        q.src0 = reinterpret_cast<const float*>(16); q.src1 = o.src1 ? reinterpret_cast<const float*>(16) : nullptr; q.c0 = src.c; q.c1 = o.src1 ? o.src1->c : 0;
+        q.rows = rows; q.h = h; q.w = w; q.up = o.up; q.taps = W.taps; q.cout = W.cout; q.prec = VH_PREC_BF16X3; q.kernel = VH_CONV_GLDS256; q.epi = o.epi; q.res_up = o.res_up;
+        if (vh_conv_takes_patch(&q) == 1) {
+            CatState& st = n->cat.at(o.sink_j);
+            const int Ct = st.Na + st.Nb;
+            if (!st.cs.ok()) { st.cs = alloc(n, st.rows, st.R, st.R, Ct); if (st.raw) st.craw = alloc(n, st.rows, st.R, st.R, Ct); }
+            const int off = o.sink_half == 0 ? 0 : st.Na;
+            const float scale = o.sink_half == 0 ? st.sc0 : st.sc1;
+            (o.sink_half == 0 ? st.x_done : st.skip_done) = true;
+            sinks[0] = vh_s8_sink{ptr(n, st.cs), Ct, off, scale, 1};
+            if (st.raw) sinks[1] = vh_s8_sink{ptr(n, st.craw), Ct, off, scale, 0};
+            sunk = true;
+        }
+    }
+    const bool skip_fp32 = sunk && o.fp32_optional && !o.also_s8 && !o.s8_only;
     if ((o.s8_only || o.also_s8) && !o.qkv) out8 = alloc(n, rows, h, w, W.cout);
-    if (!o.s8_only && !o.qkv) { if (o.out) out = *o.out; else out = alloc(n, rows, h, w, W.cout); }
+    if (!o.s8_only && !o.qkv && !skip_fp32) { if (o.out) out = *o.out; else out = alloc(n, rows, h, w, W.cout); }
     vh_conv_args a{};
     a.src0 = ptr(n, src); a.src1 = o.src1 ? ptr(n, *o.src1) : nullptr; a.c0 = src.c; a.c1 = o.src1 ? o.src1->c : 0; a.scale0 = 1.f; a.scale1 = 1.f;
     a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = VH_PRO_NONE;
@@ -225,7 +250,9 @@ std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, i
     a.prec = VH_PREC_BF16X3; a.kernel = VH_CONV_GLDS256; a.epi = o.epi; a.cvec = o.cvec; a.cvec_ld = o.cvec_ld;
     a.res = o.res ? ptr(n, *o.res) : nullptr; a.res_up = o.res_up; a.res_scale = o.res_scale ? ptr(n, *o.res_scale) : nullptr; a.ta = o.ta; a.tb = o.tb; a.clip = o.clip; a.qkv = o.qkv;
     a.stagger = 0; a.korder = VH_KORDER_AUTO; a.tile = VH_TILE_AUTO;
+    a.sink[0] = sinks[0]; a.sink[1] = sinks[1];
     call(n, vh_conv, a);
+    if (skip_fp32) out = ghost(W.cout);
     return {out, out8};
 }
 // fp32 NHWC (1-2 sources, mp_cat weights) -> S8; raw_too: second S8 output without the prologue
@@ -239,13 +266,21 @@ std::pair<Buf, Buf> split(vh_net* n, const Buf& s0, float sc0, const Buf* s1, fl
     call(n, vh_split, a);
     return {out, raw};
 }
+// vh_split of ONE half of a concat input into its channel range of the S8 concat tensors (the other half came from a sink)
+void split_half(vh_net* n, const Buf& src, float scale, const CatState& st, int off, long long npix) {
+    vh_split_args a{};
+    a.src0 = ptr(n, src); a.src1 = nullptr; a.c0 = src.c; a.c1 = 0; a.scale0 = scale; a.scale1 = 1.f; a.pro = VH_PRO_SILU; a.npix = npix; a.c_pad = src.c;
+    a.out = ptr(n, st.cs); a.out_raw = ptr(n, st.craw); a.out_c_total = st.Na + st.Nb; a.out_c_off = off;
+    call(n, vh_split, a);
+}
 void mp_sum_coeffs(double t, float& a, float& b) { const double nn = std::sqrt((1.0 - t) * (1.0 - t) + t * t); a = (float)((1.0 - t) / nn); b = (float)(t / nn); }
 
 using Feat = FeatBuf;
 
 // Block.forward :165-206 / XAttnBlock.forward :251-315 (bf16x3 path of engine.Engine._block)
 std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, int rows, const Buf& x, const Buf* skip, const Buf& cvec_all,
-                          const vh_net::EmbW& emb, const Feat* feat, int nsrc, float n_zero, bool want_s8) {
+                          const vh_net::EmbW& emb, const Feat* feat, int nsrc, float n_zero, bool want_s8, int cat_j = -1, int out_sink_j = -1, int out_sink_half = 0,
+                          bool fp32_optional = false) {
     const vh_net_config& cfg = n->cfg;
     const std::string p = prefix + (b.dec ? "dec." : "enc.") + b.name + ".";
     const int R = b.res, C = b.cout, D = b.heads ? C / b.heads : 0;
@@ -255,6 +290,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
     const float clip = cfg.clip_act > 0.0 ? (float)cfg.clip_act : 0.f, clip_res = b.heads ? 0.f : clip;
     const bool has_skip_conv = b.cin != b.cout;
     const bool res1_s8 = b.heads > 0, fin_s8 = want_s8 && !b.heads;
+    if (b.heads) { out_sink_j = -1; fp32_optional = false; }      // (the block's last op is attn_proj, a 1x1 convolution: no sinks there)
     const long long npix = (long long)rows * R * R;
     Buf out, r_s8, out_s8;
     if (!b.dec) {
@@ -280,7 +316,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         Buf y = conv(n, xs, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
         release(n, xs);
         ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = xn.ok() ? &xn : &x; o1.res_scale = res_scale.ok() ? &res_scale : nullptr;
-        o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+        o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8; o1.sink_j = out_sink_j; o1.sink_half = out_sink_half;
         auto r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
         release(n, y); release(n, xn); release(n, res_scale);
         out = r.first; r_s8 = r.second;
@@ -294,7 +330,16 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         }
         const long long npix_in = up ? npix / 4 : npix;
         const int Rin = up ? R / 2 : R;
-        auto cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, has_skip_conv);
+        std::pair<Buf, Buf> cs;
+        CatState* st = (cat_j >= 0 && skip) ? &n->cat.at(cat_j) : nullptr;
+        if (st && (st->x_done || st->skip_done)) {
+            // at least one half of mp_silu(mp_cat(x, skip)) was written by its producer (vh_s8_sink); vh_split fills in the other, if any
+            if (!st->x_done) split_half(n, x, st->sc0, *st, 0, npix_in);
+            if (!st->skip_done) split_half(n, *skip, st->sc1, *st, st->Na, npix_in);
+            cs = {st->cs, st->craw};
+        } else {
+            cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, has_skip_conv);
+        }
         ConvOpt o0; o0.up = up; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
         Buf y = conv(n, cs.first, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
         release(n, cs.first);
@@ -302,10 +347,12 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         if (has_skip_conv) {
             // conv_res1 + conv_skip as one GEMM: the raw concat is the 1-tap tail segment, ta / tb are folded into the weights
             ConvOpt o1; o1.epi = VH_EPI_STORE; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8; o1.src1 = &cs.second;
+            o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
             r = conv(n, y, n->W.at(p + "conv_res1+skip"), rows, R, R, o1);
             release(n, cs.second);
         } else {
             ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = &x; o1.res_up = up; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+            o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
             r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
         }
         release(n, y);
@@ -395,34 +442,71 @@ Buf run_unet(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net:
         if (b.xattn) { if (feats) f = &(*feats)[fi]; ++fi; }
         return f;
     };
-    for (const Block& b : sp.enc) {
+    // decoder concat inputs written by their producers: which encoder entry each skip-taking decoder block pops (UNet.forward's skip stack,
+    // training/models.py:507-510), its two channel counts and mp_cat weights (:78-84), whether conv_skip needs the raw form too
+    n->cat.clear();
+    std::map<int, int> consumer;          // encoder entry index -> decoder block index
+    {
+        int k = (int)sp.enc.size() - 1, cprev = sp.enc.back().cout;
+        const double t = n->cfg.concat_balance;
+        for (int j = 0; j < (int)sp.dec.size(); ++j) {
+            const Block& b = sp.dec[j];
+            if (!b.live) break;
+            if (b.takes_skip) {
+                CatState st; st.rows = rows; st.R = b.res; st.Nb = sp.enc[k].cout; st.Na = b.cin - st.Nb;
+                const double Cc = std::sqrt((double)(st.Na + st.Nb) / ((1 - t) * (1 - t) + t * t));
+                st.sc0 = (float)(Cc / std::sqrt((double)st.Na) * (1 - t)); st.sc1 = (float)(Cc / std::sqrt((double)st.Nb) * t);
+                st.raw = b.cin != b.cout; st.ok = st.Na % 32 == 0 && st.Nb % 32 == 0 && b.resample != 1 && st.Na == cprev;
+                n->cat[j] = st;
+                consumer[k] = j;
+                --k;
+            }
+            cprev = b.cout;
+        }
+    }
+    const int fuse = vh_knob(VH_KNOB_FUSE_CONCAT);
+    if (fuse <= 0) { n->cat.clear(); consumer.clear(); }
+    auto skip_sink = [&](int ei) { auto it = consumer.find(ei); return (fuse >= 2 && it != consumer.end() && n->cat.at(it->second).ok) ? it->second : -1; };
+    for (int ei = 0; ei < (int)sp.enc.size(); ++ei) {
+        const Block& b = sp.enc[ei];
         Buf nx;
         if (b.conv) {
             auto xs8 = split(n, x, 1.f, nullptr, 1.f, (long long)rows * b.res * b.res, rows, b.res, b.res, VH_PRO_NONE, false);
-            nx = conv(n, xs8.first, n->W.at(prefix + "enc." + b.name + ".weight"), rows, b.res, b.res, ConvOpt{}).first;
+            ConvOpt oc; oc.sink_j = skip_sink(ei); oc.sink_half = 1;
+            nx = conv(n, xs8.first, n->W.at(prefix + "enc." + b.name + ".weight"), rows, b.res, b.res, oc).first;
             release(n, xs8.first);
             release(n, x);
         } else {
             const Feat* f = next_feat(b);
-            auto r = block(n, prefix, b, rows, x, nullptr, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0);
+            auto r = block(n, prefix, b, rows, x, nullptr, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0, -1, skip_sink(ei), 1, false);
             nx = r.first;
             if (collect && b.heads > 0) out_feats->push_back(Feat{r.first, r.second});
+            // x was the output of entry ei-1; if its skip half already sits in its consumer's concat tensors, this block was its last fp32 reader
+            auto pj = consumer.find(ei - 1);
+            if (pj != consumer.end() && n->cat.at(pj->second).skip_done && x.ok() && !kept(x) && !skips.empty() && skips.back().off == x.off) {
+                release(n, x);
+                skips.back() = ghost(x.c);
+            }
         }
         skips.push_back(nx);
         x = nx;
     }
-    for (const Block& b : sp.dec) {
+    for (int j = 0; j < (int)sp.dec.size(); ++j) {
+        const Block& b = sp.dec[j];
         if (!b.live) break;
         Buf skip; const Buf* sk = nullptr;
         if (b.takes_skip) { skip = skips.back(); skips.pop_back(); sk = &skip; }
         const Feat* f = next_feat(b);
-        auto r = block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0);
-        if (!kept(x) && !in_skips(x)) release(n, x);
-        if (sk && !kept(skip) && !in_skips(skip) && skip.off != x.off) release(n, skip);
+        // this block's result is the x half of the NEXT block's concat input, and nothing else reads it
+        const Block* nb = (j + 1 < (int)sp.dec.size() && sp.dec[j + 1].live) ? &sp.dec[j + 1] : nullptr;
+        const bool xs_ok = nb && nb->takes_skip && n->cat.count(j + 1) && n->cat.at(j + 1).ok && !b.heads;
+        auto r = block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0, n->cat.count(j) ? j : -1, xs_ok ? j + 1 : -1, 0, xs_ok);
+        if (x.ok() && !kept(x) && !in_skips(x)) release(n, x);
+        if (sk && skip.ok() && !kept(skip) && !in_skips(skip) && skip.off != x.off) release(n, skip);
         if (collect && b.heads > 0) out_feats->push_back(Feat{r.first, r.second});
         x = r.first;
     }
-    for (auto& s : skips) if (!kept(s) && s.off != x.off) release(n, s);
+    for (auto& s : skips) if (s.ok() && !kept(s) && s.off != x.off) release(n, s);
     return x;
 }
 

@@ -89,6 +89,14 @@ class Buf:
         return backing[self.off:self.off + self.numel].view(self.shape)
 
 
+class Ghost:
+    """A tensor that was never materialised in fp32: its only reader takes the S8 forms its producer wrote (vh_s8_sink)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self.off = None
+
+
 @dataclass
 class Weight:
     wt: torch.Tensor
@@ -131,6 +139,13 @@ class Engine:
         self.fuse_skip = os.environ.get("VIVID_FUSE_SKIP", "1") != "0"
         # plain encoder blocks: residual of conv_res1 as x * scale[pixel] instead of a stored pixel-normalised copy
         self.scale_residual = os.environ.get("VIVID_SCALE_RESIDUAL", "1") != "0"
+        # decoder blocks: the two halves of `mp_silu(mp_cat(x, skip))` (training/models.py:78-84, :174) written in S8 form by the convolutions that
+        # PRODUCE x and skip (vh_s8_sink, patch-resident kernel) instead of by a vh_split pass over their fp32 results
+        # (VIVID_FUSE_CONCAT: 2 both halves, 1 the x half only, 0 never; unset = the library's knob default, 0: measured +0.35 % (C2) / +1.4 % (C4)
+        #  whole-step at -3..5 % of the convolutions' rate - the bytes move into epilogues that are exposed.  The knob is process-wide and is what
+        #  the C-level walk vh_net_* reads, so the two walks stay identical.)
+        self.fuse_concat = int(os.environ["VIVID_FUSE_CONCAT"]) if "VIVID_FUSE_CONCAT" in os.environ else None
+        self._cat: Dict[int, dict] = {}
         self.cfg = cfg
         self.std_filter = tuple(float(v) for v in cfg.resample_filter) == (1.0, 1.0)
         self.dual = dual_source
@@ -309,7 +324,7 @@ class Engine:
         return Buf(self._A.alloc(n), tuple(shape), self._A)
 
     def _free(self, b: Optional[Buf]):
-        if b is not None:
+        if b is not None and not isinstance(b, Ghost):
             self._A.release(b.off, b.numel)
 
     def _call(self, name, args, desc: str = ""):
@@ -324,19 +339,29 @@ class Engine:
 
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
               cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0, res_scale: Optional[Buf] = None,
-              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False, qkv=None):
+              ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False, qkv=None,
+              sink_plan: Optional[Tuple[int, str]] = None, fp32_optional=False):
         """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8;
         also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned.
         qkv (L.QkvEpilogue): the result goes straight into attention operand buffers (VH_EPI_QKV); nothing is returned."""
         out_s8 = None
         if qkv is not None:
             epi = L_EPI_QKV
-        if (s8_only or also_s8) and qkv is None:
-            out_s8 = self._alloc(rows, h, w, W.cout)
-        if not s8_only and out is None and qkv is None:
-            out = self._alloc(rows, h, w, W.cout)
         s0, sc0 = srcs[0]
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
+        # sink_plan = (dec block index, "x" | "skip"): this result is one half of that block's concat input.  If the launch takes the patch-resident
+        # kernel (the library's own rule: vh_conv_takes_patch), it writes the S8 forms itself (fp32_optional: and nothing else reads the fp32 form)
+        sinks = None
+        if sink_plan is not None and prec and self.glds and self.hook is None and qkv is None:
+            q = L.ConvArgs(src0=16, src1=16 if s1 is not None else None, c0=s0.shape[-1], c1=s1.shape[-1] if s1 is not None else 0, rows=rows, h=h, w=w,
+                           up=up, taps=W.taps, cout=W.cout, prec=prec, kernel=1, epi=epi, res_up=res_up)
+            if L.lib().vh_conv_takes_patch(C.byref(q)) == 1:
+                sinks = self._cat_sinks(*sink_plan)
+        skip_fp32 = sinks is not None and fp32_optional and not also_s8 and not s8_only
+        if (s8_only or also_s8) and qkv is None:
+            out_s8 = self._alloc(rows, h, w, W.cout)
+        if not s8_only and out is None and qkv is None and not skip_fp32:
+            out = self._alloc(rows, h, w, W.cout)
         a = L.ConvArgs(src0=s0.ptr, src1=s1.ptr if s1 is not None else None,
                        c0=s0.shape[-1], c1=s1.shape[-1] if s1 is not None else 0,
                        scale0=sc0, scale1=sc1, rows=rows, h=h, w=w, up=up, taps=W.taps, pro=pro,
@@ -351,12 +376,72 @@ class Engine:
                        ta=ta, tb=tb, clip=clip,
                        qkv=C.addressof(qkv) if qkv is not None else None,
                        stagger=self.conv_stagger if (prec and self.glds) else 0)
-        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}")
+        for i, (buf, ct, off, scale, silu) in enumerate(sinks or []):
+            a.sink[i] = L.S8Sink(ptr=buf.ptr, c_total=ct, c_off=off, scale=scale, silu=silu)
+        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}"
+                   + (f" sinks={len(sinks)}" if sinks else ""))
+        if skip_fp32:
+            return Ghost((rows, h, w, W.cout))
         if qkv is not None:
             return None
         if also_s8:
             return out, out_s8
         return out_s8 if s8_only else out
+
+    # ---- decoder concat inputs written by their producers -------------------------------------------------------------------------
+    FUSE_CONCAT_DEFAULT = 0          # == the library's default of knob "fuse_concat" (csrc/api.hip); see DESIGN.md 3 for the A/B that set it
+
+    def _fuse_mode(self) -> int:
+        if self.fuse_concat is None:
+            return self.FUSE_CONCAT_DEFAULT
+        L.set_knob("fuse_concat", self.fuse_concat)
+        return self.fuse_concat
+
+    def _cat_plan(self, spec: UNetSpec, rows: int):
+        """Per decoder block that takes a skip: which encoder entry it pops (UNet.forward's skip stack, training/models.py:507-510), the two
+        channel counts, the mp_cat weights (:78-84) and whether conv_skip needs the raw form too.  Returns (plan by dec index, consumer dec
+        index by enc entry index)."""
+        plan, consumer = {}, {}
+        k = len(spec.enc) - 1
+        cprev = spec.enc[-1].cout
+        t = self.cfg.concat_balance
+        for j, b in enumerate(spec.dec):
+            if not b.live:
+                break
+            if b.takes_skip:
+                Nb = spec.enc[k].cout
+                Na = b.cin - Nb
+                Cc = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
+                plan[j] = dict(rows=rows, R=b.res, Na=Na, Nb=Nb, sc0=Cc / math.sqrt(Na) * (1 - t), sc1=Cc / math.sqrt(Nb) * t,
+                               raw=b.cin != b.cout, cs=None, craw=None, x_done=False, skip_done=False,
+                               ok=Na % 32 == 0 and Nb % 32 == 0 and b.resample != "up" and Na == cprev)
+                consumer[k] = j
+                k -= 1
+            cprev = b.cout
+        return plan, consumer
+
+    def _cat_sinks(self, j: int, half: str):
+        """The sink list of the convolution that produces half `half` of dec block j's concat input; allocates the S8 concat tensors."""
+        st = self._cat[j]
+        Ct = st["Na"] + st["Nb"]
+        if st["cs"] is None:
+            st["cs"] = self._alloc(st["rows"], st["R"], st["R"], Ct)
+            if st["raw"]:
+                st["craw"] = self._alloc(st["rows"], st["R"], st["R"], Ct)
+        off, scale = (0, st["sc0"]) if half == "x" else (st["Na"], st["sc1"])
+        st[half + "_done"] = True
+        out = [(st["cs"], Ct, off, scale, 1)]
+        if st["raw"]:
+            out.append((st["craw"], Ct, off, scale, 0))
+        return out
+
+    def _split_half(self, src: Buf, scale: float, st: dict, off: int):
+        """vh_split of ONE half of a concat input into its channel range of the S8 concat tensors (the other half came from a sink)."""
+        rows, h, w, c = src.shape
+        Ct = st["Na"] + st["Nb"]
+        self._call("vh_split", L.SplitArgs(src0=src.ptr, src1=None, c0=c, c1=0, scale0=scale, scale1=1.0, pro=L_PRO_SILU, npix=rows * h * w, c_pad=c,
+                                          out=st["cs"].ptr, out_raw=st["craw"].ptr if st["craw"] is not None else None, out_c_total=Ct, out_c_off=off),
+                   f"rows={rows} {h}x{w} c={c} raw={int(st['craw'] is not None)} half@{off}/{Ct}")
 
     def _split(self, srcs: Sequence[Tuple[Buf, float]], pro: int, raw_too: bool = False):
         """fp32 NHWC (1-2 sources, mp_cat weights) -> S8 at the sources' resolution, channels padded to 32.
@@ -396,7 +481,8 @@ class Engine:
     # ------------------------------------------------------------------ one block
     def _block(self, prefix: str, grp: str, b: BlockSpec, rows: int, x: Buf, skip: Optional[Buf],
                cvec_all: Buf, cols: Dict[str, int], total_cols: int,
-               feat: Optional[Buf], feat_s8: Optional[Buf], n_zero: float, want_s8: bool = False):
+               feat: Optional[Buf], feat_s8: Optional[Buf], n_zero: float, want_s8: bool = False,
+               cat_j: Optional[int] = None, out_sink: Optional[Tuple[int, str]] = None, fp32_optional: bool = False):
         """Block.forward :165-206 / XAttnBlock.forward :251-315.  x is the block input (before
         resampling); returns (block output fp32, its S8 copy or None).  Neither x nor skip is released here.
         In bf16x3 mode every conv reads an S8 (bf16 hi/lo) tensor written by the op that produced it."""
@@ -416,6 +502,8 @@ class Engine:
         out_s8 = None
         res1_s8 = bool(b.heads) and ax3                 # conv_res1's result also feeds attn_qkv -> S8 copy
         fin_s8 = want_s8 and x3 and not b.heads         # no attention: conv_res1's result is the block output
+        if b.heads or not x3:
+            out_sink, fp32_optional = None, False       # (the block's last op is attn_proj, a 1x1 convolution: no sinks there)
         if b.flavor == "enc":
             xs = self._alloc(rows, R, R, C) if x3 else None      # S8 of mp_silu(xn): conv_res0's input
             xs_ptr = xs.ptr if xs is not None else None
@@ -449,7 +537,7 @@ class Engine:
             else:
                 y = self._conv([(xn, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, pro=L_PRO_SILU, epi=L_EPI_SCALE_SILU, cvec=cv)
             r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=xn if xn is not None else res_src,
-                           res_scale=res_scale, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
+                           res_scale=res_scale, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8, sink_plan=out_sink)
             self._free(y)
             self._free(xn)
             self._free(res_scale)
@@ -467,12 +555,21 @@ class Engine:
             else:
                 srcs = [(x, 1.0)]
             craw = None
-            if x3:
+            st = self._cat.get(cat_j) if (cat_j is not None and skip is not None) else None
+            if x3 and st is not None and (st["x_done"] or st["skip_done"]):
+                # at least one half of mp_silu(mp_cat(x, skip)) was written by its producer (vh_s8_sink); vh_split fills in the other, if any
+                if not st["x_done"]:
+                    self._split_half(x, st["sc0"], st, 0)
+                if not st["skip_done"]:
+                    self._split_half(skip, st["sc1"], st, st["Na"])
+                cs, craw = st["cs"], st["craw"]
+            elif x3:
                 # mp_silu(mp_cat(...)) once per element as S8; the raw split is conv_skip's input
                 if has_skip_conv:
                     cs, craw = self._split(srcs, L_PRO_SILU, raw_too=True)
                 else:
                     cs = self._split(srcs, L_PRO_SILU)
+            if x3:
                 y = self._conv([(cs, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, up=up,
                                epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True)
                 self._free(cs)
@@ -482,7 +579,7 @@ class Engine:
             if has_skip_conv and x3 and self._fused_skip(b):
                 # conv_res1 + conv_skip as one GEMM: the raw concat enters as the 1-tap tail of the K loop, ta / tb are in the weights
                 r = self._conv([(y, 1.0), (craw, 1.0)], self.W[p + "conv_res1+skip"], rows, R, R, epi=L_EPI_STORE, clip=clip_res, prec=1,
-                               also_s8=res1_s8 or fin_s8)
+                               also_s8=res1_s8 or fin_s8, sink_plan=out_sink, fp32_optional=fp32_optional)
                 self._free(craw)
                 xsk = None
             else:
@@ -497,7 +594,8 @@ class Engine:
                     assert skip is None
                     xsk, res, res_up = None, x, up
                 r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
-                               res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8)
+                               res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8, sink_plan=out_sink,
+                               fp32_optional=fp32_optional)
             self._free(y)
             self._free(xsk)
             self._free(xup)
@@ -507,7 +605,8 @@ class Engine:
             out, r_s8 = r, None
         if fin_s8:
             out_s8 = r_s8
-        self._tap(p + "res", out)
+        if not isinstance(out, Ghost):
+            self._tap(p + "res", out)
         if b.heads:
             S = R * R
             use_feat = b.xattn and feat is not None
@@ -566,7 +665,8 @@ class Engine:
             if emit:
                 out_s8 = r2[1]
             self._free(att)
-        self._tap(p + "out", out)
+        if not isinstance(out, Ghost):
+            self._tap(p + "out", out)
         return out, out_s8
 
     # ------------------------------------------------------------------ embeddings
@@ -602,6 +702,14 @@ class Engine:
         out_feats: List[Tuple[Buf, Optional[Buf]]] = []
         fi = 0
         x = x_in
+        self._cat, consumer = {}, {}
+        fuse = self._fuse_mode()
+        if self.x3 and self.glds and fuse > 0 and self.hook is None:
+            self._cat, consumer = self._cat_plan(spec, rows)
+
+        def skip_sink(ei):
+            j = consumer.get(ei)
+            return (j, "skip") if fuse >= 2 and j is not None and self._cat[j]["ok"] else None
 
         def kept(buf):
             return any(buf is f[0] for f in out_feats)
@@ -615,11 +723,11 @@ class Engine:
                 fi += 1
             return f
 
-        for b in spec.enc:
+        for ei, b in enumerate(spec.enc):
             if b.kind == "conv":
                 if self.x3:
                     xs8 = self._split([(x, 1.0)], 0)
-                    nx = self._conv([(xs8, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res, prec=1)
+                    nx = self._conv([(xs8, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res, prec=1, sink_plan=skip_sink(ei))
                     self._free(xs8)
                 else:
                     nx = self._conv([(x, 1.0)], self.W[f"{prefix}enc.{b.name}.weight"], rows, b.res, b.res)
@@ -628,18 +736,27 @@ class Engine:
             else:
                 f32, f8 = next_feat(b)
                 nx, nx8 = self._block(prefix, "enc", b, rows, x, None, cvec, cols, total, f32, f8, n_zero,
-                                      want_s8=collect and b.heads > 0)
+                                      want_s8=collect and b.heads > 0, out_sink=skip_sink(ei))
                 if collect and b.heads > 0:
                     out_feats.append((nx, nx8))
+                # x was the output of entry ei-1; if its skip half already sits in its consumer's concat tensors, this block was its last fp32 reader
+                pj = consumer.get(ei - 1)
+                if pj is not None and self._cat[pj]["skip_done"] and not kept(x) and skips and skips[-1] is x:
+                    self._free(x)
+                    skips[-1] = Ghost(x.shape)
             skips.append(nx)
             x = nx
-        for b in spec.dec:
+        for j, b in enumerate(spec.dec):
             if not b.live:
                 break
             skip = skips.pop() if b.takes_skip else None
             f32, f8 = next_feat(b)
+            # this block's result is the x half of the NEXT block's concat input, and nothing else reads it
+            nb_ = spec.dec[j + 1] if j + 1 < len(spec.dec) and spec.dec[j + 1].live else None
+            xs_ok = nb_ is not None and nb_.takes_skip and (j + 1) in self._cat and self._cat[j + 1]["ok"] and not b.heads
             nx, nx8 = self._block(prefix, "dec", b, rows, x, skip, cvec, cols, total, f32, f8, n_zero,
-                                  want_s8=collect and b.heads > 0)
+                                  want_s8=collect and b.heads > 0, cat_j=j if j in self._cat else None,
+                                  out_sink=(j + 1, "x") if xs_ok else None, fp32_optional=xs_ok)
             for old in (x, skip):
                 if old is not None and not kept(old) and all(old is not s_ for s_ in skips):
                     self._free(old)
