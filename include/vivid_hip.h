@@ -365,6 +365,8 @@ typedef struct {
     float* grid_feat; float* warp_feat;
     const float* nonzero_flag;   /* optional, from vh_nonzero_flag over src[:, :3]: when it reads 0 (the source is all zero) both
                                     outputs are zero grids, the shortcut of training/models.py:647-648, decided on the device */
+    float* uv_out;               /* optional [rows][s][s][2]: the warped coordinates (row, column) themselves, before the Fourier embedding
+                                    (warp_image training/utils.py:189-201) - what tests hold against an fp64 evaluation */
 } vh_warp_args;
 int vh_warp_features(vh_ctx* ctx, const vh_warp_args* a);
 

@@ -14,6 +14,8 @@ BASELINE.json configuration is therefore pinned in two links:
 Reference path: NVPrecond._forward_dualsource training/models.py:628-689; the guided closure generate_images.py:55-62.
 Host cost on the GPU box: three oracle evaluations (C2 net + guidance net ~70 s, C4 ~70 s, C5 ~45 s).
 """
+import math
+
 import pytest
 import torch
 
@@ -153,7 +155,7 @@ def test_config4_sr_1024_vs_oracle_and_timed_batch():
 # ------------------------------------------------------------------------------------------------ C5 (base + depth-warp features)
 def test_config5_depth_warp_256_vs_oracle_and_timed_batch():
     """BASELINE configs[4]: base architecture + depth-warp Fourier features at 256^2 (132-channel first convolutions,
-    get_warped_features training/utils.py:204-216).  Batch 1 against the oracle in both modes; batch 16 against batch 1."""
+    get_warped_features training/utils.py:204-216).  Batch 1 against the oracle; batch 16 against batch 1."""
     import vivid_amd
     from vivid_amd.geometry import compose_geometry
     B = 16
@@ -171,17 +173,64 @@ def test_config5_depth_warp_256_vs_oracle_and_timed_batch():
         ref = R.nvprecond_forward(sd, _ocfg(cfg), src[:2], x[:2], sig[:2], geo[:2])
     full, singles = _check_batch_vs_singles(net, src, x, sig, geo, None, (0, 7, 15))
     assert full.shape == (B, 3, 256, 256)
-    del net
-    torch.cuda.empty_cache()
-    net32, _ = _net(cfg, 0, "fp32")
-    D32 = net32(*_cuda(src[:2], x[:2], sig[:2], geo[:2])).cpu()
-    # Tolerance vs the oracle: 2e-4 here, not 1e-4 / 2e-5.  The network INPUT of this configuration is cos(2 pi f u + phase) of the
-    # warped pixel coordinate u <= 256 with f ~ N(0,1) (MPFourier on get_warped_features, training/utils.py:204-216): in fp32 ONE ulp
-    # of u moves the feature tensor by 8.4e-5 rel-L2 (and fp32 evaluation is 3.7e-5 from the fp64 value), so the reference's own
-    # result is defined to ~1e-4 only - the oracle's u (torch.linalg / bmm op order) and the kernel's (closed-form inverse) differ in
-    # the last bit.  Measured: both arithmetic modes land 8e-5 from the oracle and 1e-5 from each other, which is the check that
-    # the kernels, not the input's conditioning, are exact to the usual bar.
+    # Tolerance vs the oracle: 2e-4 here, not 1e-4.  DERIVED, not argued: test_warp_kernel_against_fp64 (below) holds the kernel's warped
+    # coordinates to the fp64 value within 3 ulp of the image scale - no worse than the oracle's own fp32 evaluation - and measures what that
+    # does to this configuration's network INPUT, cos(f u + phase) of a coordinate u <= 256 with f ~ 2 pi N(0,1) (MPFourier on
+    # get_warped_features, training/utils.py:204-216): either fp32 evaluation sits 4-5e-5 (rel-L2) from the fp64 features, so two correct fp32
+    # evaluations differ by up to ~9e-5 in the input, and D_x by about as much (measured 8e-5).  2e-4 is 2x that, 5x inside north_star's 1e-3.
+    # (The exact-fp32 mode of this configuration used to be run here as a cross-check, 1e-5 from bf16x3; the fp64 test replaces it.)
     assert rel_l2(singles[0], ref) < 2e-4
     assert rel_l2(full[:1], ref) < 2e-4
-    assert rel_l2(D32, ref) < 2e-4
-    assert rel_l2(singles[0], D32) < 3e-5
+
+
+def test_warp_kernel_against_fp64():
+    """vh_warp_features at C5's geometry (256^2, depth U(1,5), small rotation + translation) against an fp64 evaluation of the oracle's
+    get_warped_features / warp_image (training/utils.py:189-216): the warped coordinates themselves (vh_warp_args.uv_out) and the 2 x 64
+    Fourier channels per grid.  Pins the KERNEL, where the C5 test above can only see the network's sensitivity to its input:
+      * (u, v) within 3 ulp(fp32) of the image scale (ulp(256) = 3.05e-5; measured max 2.1, p99.9 1.1) and no worse than the oracle's own
+        fp32 evaluation at any quantile (torch.inverse + matmul: max 2.4 ulp);
+      * feature tensor within 6e-5 rel-L2 of the fp64 features (measured 4.5e-5), made of the coordinate error (4.0e-5) and of evaluating
+        cos(f u + phase) in fp32 at |f u| up to ~5000 rad (3.7e-5 even from EXACT coordinates; a 1-ulp change of u moves it by 7e-5).
+    (tools/micro/warp_fp64_probe.py prints the same numbers; profiles/r04_warp_kernel_vs_fp64.txt)"""
+    from vivid_amd import _lib as L
+    from vivid_amd.geometry import compose_geometry, geometry_stats
+    rows, S = 4, 256
+    g = torch.Generator().manual_seed(6)
+    depth = torch.rand(rows, 1, S, S, generator=g) * 4 + 1
+    th = 0.05 * torch.randn(rows, generator=g)
+    Rm = torch.zeros(rows, 3, 3)
+    Rm[:, 0, 0], Rm[:, 0, 2], Rm[:, 1, 1], Rm[:, 2, 0], Rm[:, 2, 2] = th.cos(), th.sin(), 1.0, -th.sin(), th.cos()
+    K = (torch.tensor([57.7, 57.7, 32.0, 32.0]) * 4).expand(rows, 4)
+    geo = compose_geometry(torch.cat([Rm, 0.1 * torch.randn(rows, 3, 1, generator=g)], dim=2), K, K, imsize=S)
+    freqs, phases = 2 * math.pi * torch.randn(128, generator=g), 2 * math.pi * torch.rand(128, generator=g)
+    ctx = L.Context(torch.cuda.current_stream().cuda_stream)
+    src = torch.cat([torch.rand(rows, 3, S, S, generator=g), depth], 1).cuda()
+    gf, wf = torch.empty(rows, S, S, 128, device="cuda"), torch.empty(rows, S, S, 128, device="cuda")
+    uv = torch.empty(rows, S, S, 2, device="cuda")
+    mean, std = geometry_stats(S)
+    gd, fd, pd = geo.cuda(), freqs.cuda(), phases.cuda()
+    wa = L.WarpArgs(depth=src.data_ptr(), src_c=4, depth_ch=3, geometry=gd.data_ptr(), freqs=fd.data_ptr(), phases=pd.data_ptr(), rows=rows, s=S,
+                    grid_feat=gf.data_ptr(), warp_feat=wf.data_ptr(), nonzero_flag=None, uv_out=uv.data_ptr())
+    for i in range(20):
+        wa.mean[i], wa.std[i] = float(mean[i]), float(std[i])
+    ctx.call("vh_warp_features", wa)
+    torch.cuda.synchronize()
+    ar = torch.arange(0, S, dtype=torch.float64)
+    ii, jj = torch.meshgrid(ar, ar, indexing="ij")
+    grid = torch.stack([ii, jj], -1)[None].repeat(rows, 1, 1, 1) + 0.5
+    uv64 = R.warp_grid(depth.double().permute(0, 2, 3, 1), geo.double(), grid)            # the reference's formula, evaluated in fp64
+    uvo = R.warp_grid(depth.permute(0, 2, 3, 1), geo, grid.float()).double()              # ... and as the reference runs it: fp32
+    ulp = 2.0 ** -15                                                                        # ulp(fp32) of a coordinate in [256, 512)
+    assert float(uv64.abs().max()) < 512
+    ae, aeo = (uv.cpu().double() - uv64).abs().flatten(), (uvo - uv64).abs().flatten()
+    assert float(ae.max()) < 3 * ulp and float(ae.quantile(0.999)) < 1.5 * ulp, (float(ae.max()) / ulp, float(ae.quantile(0.999)) / ulp)
+    for q in (0.5, 0.99, 0.999):
+        assert float(ae.quantile(q)) <= 1.25 * float(aeo.quantile(q)) + 0.25 * ulp, q
+    f64, p64 = freqs[:64].double(), phases[:64].double()
+
+    def emb(c):       # [rows, S, S, 2] -> [rows, S, S, 128], channel = 64 * axis + k (training/utils.py:214-215, MPFourier models.py:96-101)
+        return torch.cat([torch.cos(c[..., 0:1] * f64 + p64), torch.cos(c[..., 1:2] * f64 + p64)], -1) * math.sqrt(2)
+    exact = emb(uv64)
+    assert rel_l2(wf.cpu(), exact) < 6e-5
+    assert rel_l2(emb(uv.cpu().double()), exact) < 5.5e-5       # the coordinate error alone
+    assert rel_l2(gf.cpu(), emb(grid)) < 3e-5                   # the un-warped grid: exact coordinates, fp32 cos only

@@ -109,7 +109,7 @@ class WarpArgs(C.Structure):
     _fields_ = [("depth", C.c_void_p), ("src_c", C.c_int), ("depth_ch", C.c_int), ("geometry", C.c_void_p),
                 ("mean", C.c_float * 20), ("std", C.c_float * 20), ("freqs", C.c_void_p), ("phases", C.c_void_p),
                 ("rows", C.c_int), ("s", C.c_int), ("grid_feat", C.c_void_p), ("warp_feat", C.c_void_p),
-                ("nonzero_flag", C.c_void_p)]
+                ("nonzero_flag", C.c_void_p), ("uv_out", C.c_void_p)]
 
 
 class NonzeroArgs(C.Structure):

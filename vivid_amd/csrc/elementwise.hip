@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256) void warp_features_k(vh_warp_args a, long long
     if (a.nonzero_flag && *a.nonzero_flag == 0.f) {      // all-zero source: zero grids (training/models.py:647-648)
         a.grid_feat[i] = 0.f;
         a.warp_feat[i] = 0.f;
+        if (a.uv_out && ch < 2) a.uv_out[pix * 2 + ch] = 0.f;
         return;
     }
     const int axis = ch >> 6, kf = ch & 63;
@@ -439,6 +440,7 @@ __global__ __launch_bounds__(256) void warp_features_k(vh_warp_args a, long long
     float v = (g[17] * wy + g[19] * wz) / wz;
     if (u != u) u = 0.f;
     if (v != v) v = 0.f;
+    if (a.uv_out && ch == 0) { a.uv_out[pix * 2] = u; a.uv_out[pix * 2 + 1] = v; }
     const float f = a.freqs[kf], ph = a.phases[kf];
     const float cg = axis == 0 ? g0 : g1;
     const float cw = axis == 0 ? u : v;
