@@ -448,6 +448,18 @@ typedef struct {
 } vh_sampler_step_args;
 int vh_sampler_step(vh_ctx* ctx, const vh_sampler_step_args* a);
 
+/* ---- NHWC <-> NCHW of fp32 tensors --------------------------------------------------------------------
+ * The feature lists of `return_features` / `inject_features` are NCHW in the reference (training/models.py:664-670); the library keeps
+ * activations NHWC.  rows images of hw pixels x c channels; to_nchw = 1: [rows][hw][c] -> [rows][c][hw], 0: the other way. */
+typedef struct { const float* in; float* out; int rows, c, hw; int to_nchw; } vh_layout_args;
+int vh_layout(vh_ctx* ctx, const vh_layout_args* a);
+
+/* out[i] = a[i] + s * b[i], rounded after the multiply and after the add like torch's `a + s * b` (a NULL: s * b[i]; b NULL: the constant s):
+ * the sampler's x0 = noise * t0 and churn x + sqrt(t_hat^2 - t_cur^2) * S_noise * eps (generate_images.py:72, :81), the super-resolution
+ * conditioning noise cond + noisy_sr * eps (training/models.py:658), `torch.full`. */
+typedef struct { const float* a; const float* b; float s; float* out; size_t n; } vh_axpy_args;
+int vh_axpy(vh_ctx* ctx, const vh_axpy_args* a);
+
 /* ---- FID / PSNR statistics (calculate_metrics.py:147, 158-172) -------------------------------------------
  * vh_moments: outer[fa][fb] += A^T B and (optionally) sum_a[fa] += column sums of A, for detector features A [n][fa],
  * B [n][fb] (fp32, row-major; B may be A).  Products and sums are fp64 on v_mfma_f64_16x16x4_f64, i.e. exactly the
@@ -488,7 +500,7 @@ int vh_psnr_sum(vh_ctx* ctx, const vh_psnr_args* a);
  *   for i < vh_net_num_params(net): vh_net_param_info(net, i, &name, &ndim, shape); vh_net_bind_param(net, name, device_fp32_ptr);
  *   vh_net_prepare(net, buf, vh_net_prepared_bytes(net));                 // again after the weights change
  *   vh_net_record(net, B, workspace, vh_net_workspace_bytes(net, B));     // once per batch size
- *   vh_net_run(net, B, src, x, sigma, geometry, cond, out);               // any number of times, on the context's stream
+ *   vh_net_run(net, B, src, x, sigma, geometry, cond, cond_noise, out);   // any number of times, on the context's stream
  */
 typedef struct vh_net vh_net;
 typedef struct {
@@ -508,6 +520,8 @@ typedef struct {
     int super_res, no_time_enc, depth_input, warp_depth_coor, uncond;
     int dual_source;                           /* 1: the HEAD forward (two source rows per target), 0: the single-source forward */
     float geom_mean[20], geom_std[20];         /* warp_depth_coor only: the geometry statistics for this image size (training/utils.py:38-44, 77-78) */
+    double noisy_sr;                           /* super_res: the net sees cond + noisy_sr * N(0,1) on EVERY forward, also at inference (training/models.py:658,
+                                                  0.25 in --preset=vivid-sr).  The draws are the caller's: `cond_noise` of the run calls, required while this is != 0 */
 } vh_net_config;
 int vh_net_create(vh_ctx* ctx, const vh_net_config* cfg, vh_net** out);
 int vh_net_destroy(vh_net* net);
@@ -520,24 +534,71 @@ int vh_net_prepare(vh_net* net, void* buffer, size_t bytes);                    
 size_t vh_net_workspace_bytes(vh_net* net, int batch);                           /* 0 on error (see vh_last_error) */
 int vh_net_record(vh_net* net, int batch, void* workspace, size_t bytes);
 /* src [rows][3|4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim], cond [batch][3][R][R] (super_res),
- * out [batch][3][R][R]; rows = batch * (dual_source ? 2 : 1); device fp32, contiguous.  Odd rows of x / sigma are ignored in
- * dual-source mode, like the reference (:676-678). */
-int vh_net_run(vh_net* net, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out);
+ * cond_noise [batch][3][R][R] standard-normal draws (super_res with noisy_sr != 0, else NULL), out [batch][3][R][R];
+ * rows = batch * (dual_source ? 2 : 1); device fp32, contiguous.  Odd rows of x / sigma are ignored in dual-source mode, like the
+ * reference (:676-678). */
+int vh_net_run(vh_net* net, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+               const float* cond_noise, float* out);
 /* The two halves of an evaluation as separate programs (training/models.py:664-667 and :676-683), for samplers: the encoder sees
  * (src, sigma, geometry) only - never x - and a sampler knows its noise levels in advance, so it can evaluate the encoder ONCE per
  * level (the Heun probe of step i and the Euler call of step i+1 share one) and one level ahead on another stream.
  *   VH_NET_FEATURES  encoder only; the features stay in that program's workspace (two slots, so that one can be filled while the
  *                    other is read);
  *   VH_NET_BOUND     UNet only, reading the features of the VH_NET_FEATURES program of the same (slot, batch) in place - record that
- *                    one first.  `src` is read only by warp_depth_coor nets (may be NULL otherwise).
+ *                    one first; re-recording the VH_NET_FEATURES program drops the VH_NET_BOUND one (it holds addresses into the other's
+ *                    workspace).  `src` is read only by warp_depth_coor nets (may be NULL otherwise);
+ *   VH_NET_INJECT    UNet only, on a feature list the CALLER supplies (inject_features, :664-665), see vh_net_run_inject.
  * vh_net_encode + vh_net_run_bound == vh_net_run, bit for bit.  The two VH_NET_BOUND programs of a batch size may be recorded over the SAME
  * workspace (they are replayed one after the other and differ only in the feature pointers they read); the two VH_NET_FEATURES programs
  * need one each. */
-enum { VH_NET_FULL = 0, VH_NET_FEATURES = 1, VH_NET_BOUND = 2 };
+enum { VH_NET_FULL = 0, VH_NET_FEATURES = 1, VH_NET_BOUND = 2, VH_NET_INJECT = 3 };
 size_t vh_net_workspace_bytes_mode(vh_net* net, int mode, int batch);
 int vh_net_record_mode(vh_net* net, int mode, int slot, int batch, void* workspace, size_t bytes);
 int vh_net_encode(vh_net* net, int slot, int batch, const float* src, const float* sigma, const float* geometry);
-int vh_net_run_bound(vh_net* net, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out);
+int vh_net_run_bound(vh_net* net, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+                     const float* cond_noise, float* out);
+
+/* The rest of NVPrecond.forward's protocol (training/models.py:664-670, 685-688), for hosts that want the tensors themselves:
+ *   vh_net_num_features / vh_net_feature_shape   the encoder's feature list: entry i is [rows][channels][res][res] (rows = batch * sources)
+ *   vh_net_features      `return_features=True`: runs the VH_NET_FEATURES program of slot 0 (record it first) and writes the list as NCHW
+ *                        tensors into features_out[i] (device pointers, caller-owned)
+ *   vh_net_run_inject    `inject_features=list`: the UNet on a caller-supplied NCHW feature list (VH_NET_INJECT program of slot 0), e.g. the
+ *                        zero list, edited features, or the output of vh_net_features
+ *   vh_net_logvar        `return_logvar=True`: logvar[batch] = logvar_linear(logvar_fourier(ln(sigma)/4)) (:685-688) - a function of sigma alone;
+ *                        sigma [rows] as for vh_net_run.  Not recorded: one small launch on the context's stream. */
+int vh_net_num_features(const vh_net* net);
+int vh_net_feature_shape(const vh_net* net, int i, int* channels, int* res);
+int vh_net_features(vh_net* net, int batch, const float* src, const float* sigma, const float* geometry, float* const* features_out);
+int vh_net_run_inject(vh_net* net, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+                      const float* cond_noise, const float* const* features_in, float* out);
+int vh_net_logvar(vh_net* net, int batch, const float* sigma, float* logvar);
+
+/* ---- edm_sampler (generate_images.py:43-118) from C ------------------------------------------------------------------------------
+ * The guided Heun sampler over vh_net evaluations: rho schedule (:68-70), x0 = noise * t0 (:72), optional churn (:78-84), Euler step and
+ * Heun correction (:87-114), classifier-free guidance D = ref.lerp(D, guidance) (:58-62), dual-source row handling (:90-98, :106-111),
+ * `no_time_enc` feature reuse (:52-53) - vivid_amd.edm_sampler restated against this ABI, bit for bit (tests/test_hip_net_c.py), with its
+ * scheduling: when the VH_NET_FEATURES and VH_NET_BOUND programs of both slots are recorded for `batch`, the encoder runs once per noise
+ * level, one level ahead on a second stream; otherwise every call is a whole VH_NET_FULL evaluation.  gnet: the guidance net (an `uncond`
+ * vh_net with its VH_NET_FULL program recorded), NULL or == net for none (guidance must then be 1).
+ * Randomness is the caller's: `randn(user, dst, n, stream)` must enqueue on `stream` a fill of dst[0..n) (device) with N(0,1) draws; it is
+ * called for churn noise (n = rows*3*R*R, once per churned step) and for the super-resolution conditioning noise (n = batch*3*R*R, once per
+ * denoiser call of a net with noisy_sr != 0), in the order vivid_amd.edm_sampler consumes torch's generator.
+ * src [rows][3|4][R][R], noise [rows][3][R][R], labels [rows][source_label_dim] (NULL for none), cond [batch][3][R][R] or NULL,
+ * out [batch][3][R][R] (the even rows of the final state in dual-source mode, :116-118).  workspace: vh_edm_sampler_workspace_bytes(). */
+typedef void (*vh_randn_fn)(void* user, float* device_dst, size_t n, void* stream);
+typedef struct {
+    int num_steps;                     /* 32 */
+    double sigma_min, sigma_max, rho;  /* 0.002, 80, 7 */
+    double guidance;                   /* 1 = none */
+    double S_churn, S_min, S_max, S_noise;   /* 0, 0, inf, 1 */
+    const float* t_steps;              /* optional host array [num_steps + 1] (last = 0): these noise levels instead of the rho schedule - e.g. the
+                                          levels torch computed, for bit-compatible runs (powf of this libm vs torch's vectorised pow: 1 ulp) */
+    vh_randn_fn randn; void* randn_user;
+    int guidance_overlap;              /* -1: by size (the guidance net on a second stream when the evaluation cannot fill the chip), 0 never, 1 always */
+} vh_sampler_config;
+size_t vh_edm_sampler_workspace_bytes(const vh_net* net, int batch);
+int vh_edm_sampler(vh_net* net, vh_net* gnet, const vh_sampler_config* cfg, int batch, const float* src, const float* noise, const float* labels,
+                   const float* cond, void* workspace, size_t workspace_bytes, float* out);
 
 #ifdef __cplusplus
 }

@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
         if (!wb) { fprintf(stderr, "vh_net_workspace_bytes: %s\n", vh_last_error()); return 2; }
         void* ws; CHECK_HIP(hipMalloc(&ws, wb));
         CHECK_VH(vh_net_record(net, batch, ws, wb));
-        CHECK_VH(vh_net_run(net, batch, dev[0], dev[1], dev[2], dev[3], dev[4], out));
+        CHECK_VH(vh_net_run(net, batch, dev[0], dev[1], dev[2], dev[3], dev[4], /*cond_noise=*/NULL, out));
     } else {                               /* the sampler's split evaluation: encoder into feature slot 1, UNet on that slot in place */
         size_t fb = vh_net_workspace_bytes_mode(net, VH_NET_FEATURES, batch), bb = vh_net_workspace_bytes_mode(net, VH_NET_BOUND, batch);
         if (!fb || !bb) { fprintf(stderr, "vh_net_workspace_bytes_mode: %s\n", vh_last_error()); return 2; }
@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
         CHECK_VH(vh_net_record_mode(net, VH_NET_FEATURES, 1, batch, wf, fb));
         CHECK_VH(vh_net_record_mode(net, VH_NET_BOUND, 1, batch, wbnd, bb));
         CHECK_VH(vh_net_encode(net, 1, batch, dev[0], dev[2], dev[3]));
-        CHECK_VH(vh_net_run_bound(net, 1, batch, dev[0], dev[1], dev[2], dev[3], dev[4], out));
+        CHECK_VH(vh_net_run_bound(net, 1, batch, dev[0], dev[1], dev[2], dev[3], dev[4], /*cond_noise=*/NULL, out));
     }
     CHECK_HIP(hipDeviceSynchronize());
     float* host_out = (float*)malloc(out_n * 4);

@@ -31,7 +31,7 @@ STRUCT_MIRRORS = {"vh_prep_weight_args": "PrepWeightArgs", "vh_conv_args": "Conv
                   "vh_precond_out_args": "PrecondOutArgs", "vh_warp_args": "WarpArgs", "vh_sampler_step_args": "SamplerStepArgs",
                   "vh_qkv_epilogue": "QkvEpilogue", "vh_codec_args": "CodecArgs", "vh_add_depth_args": "AddDepthArgs",
                   "vh_resize_args": "ResizeArgs", "vh_nonzero_args": "NonzeroArgs", "vh_resample_args": "ResampleArgs",
-                  "vh_moments_args": "MomentsArgs", "vh_psnr_args": "PsnrArgs", "vh_net_config": "NetConfigC", "vh_s8_sink": "S8Sink"}
+                  "vh_moments_args": "MomentsArgs", "vh_psnr_args": "PsnrArgs", "vh_net_config": "NetConfigC", "vh_s8_sink": "S8Sink", "vh_layout_args": "LayoutArgs", "vh_axpy_args": "AxpyArgs", "vh_sampler_config": "SamplerConfigC"}
 
 
 def _header_structs():

@@ -63,6 +63,8 @@ def test_c_host_reproduces_golden_and_python(name, mode, tmp_path, golden_dir):
     from vivid_amd.cnet import c_config
     case = CASES[name]
     cfg = case["cfg"]
+    if cfg.super_res:               # (the host passes no conditioning noise: noisy_sr = 0 on both sides)
+        cfg = vivid_amd.NetConfig(**{**cfg.to_dict(), "noisy_sr": 0.0})
     sd = vivid_amd.synth_state_dict(cfg, seed=case["seed"])
     inp = make_inputs(case)
     sigma = case["sigmas"][0]

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from tests.conftest import rel_l2
-from tests.golden.cases import CASES, make_inputs, x_for
+from tests.golden.cases import CASES, make_inputs, make_randn_like, x_for
 
 pytestmark = pytest.mark.gpu
 
@@ -21,6 +21,8 @@ pytestmark = pytest.mark.gpu
 def _pair(cfg, seed, dual=True):
     import vivid_amd
     from vivid_amd.cnet import CNet
+    if cfg.super_res:               # the SR net's conditioning noise (training/models.py:658) off on both sides; test_c_net_noisy_sr_... has it on
+        cfg = vivid_amd.NetConfig(**{**cfg.to_dict(), "noisy_sr": 0.0})
     sd = vivid_amd.synth_state_dict(cfg, seed=seed)
     py = vivid_amd.NVPrecond.from_config(cfg, dual_source=dual, precision="bf16x3")
     py.load_state_dict(sd, strict=True)
@@ -108,3 +110,124 @@ def test_c_net_refuses_missing_inputs():
         cn(inp["src"], x_for(inp, 1.0), sig, None)
     with pytest.raises(L.VividHipError, match="reads src"):
         cn(None, x_for(inp, 1.0), sig, inp["geometry"])
+
+
+def test_c_net_noisy_sr_conditioning_noise():
+    """The reference adds noisy_sr * randn_like(cond) to the conditioning image on EVERY forward, also at inference (training/models.py:658;
+    0.25 in --preset=vivid-sr).  vh_net_config.noisy_sr + the `cond_noise` argument: with the draws torch would have made, the C net equals
+    vivid_amd.NVPrecond bit for bit; without them it refuses to run."""
+    import vivid_amd
+    from vivid_amd import _lib as L
+    from vivid_amd.cnet import CNet
+    case = CASES["tiny_sr"]
+    cfg = vivid_amd.NetConfig(**{**case["cfg"].to_dict(), "noisy_sr": 0.25})
+    sd = vivid_amd.synth_state_dict(cfg, seed=case["seed"])
+    py = vivid_amd.NVPrecond.from_config(cfg, precision="bf16x3")
+    py.load_state_dict(sd, strict=True)
+    py = py.cuda()
+    assert py.noisy_sr == 0.25
+    cn = CNet(cfg)
+    cn.load_state_dict(sd)
+    inp = {k: v.cuda() for k, v in make_inputs(case).items()}
+    sig = torch.full((inp["src"].shape[0],), 2.0, device="cuda")
+    x = x_for(inp, 2.0)
+    torch.manual_seed(11)
+    a = py(inp["src"], x, sig, inp["geometry"], inp["cond"])
+    torch.manual_seed(11)
+    noise = torch.randn_like(inp["cond"])
+    b = cn(inp["src"], x, sig, inp["geometry"], inp["cond"], noise)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert not torch.equal(a, cn(inp["src"], x, sig, inp["geometry"], inp["cond"], torch.zeros_like(noise)))
+    with pytest.raises(L.VividHipError, match="noisy_sr"):
+        cn(inp["src"], x, sig, inp["geometry"], inp["cond"])
+
+
+@pytest.mark.parametrize("name", ["tiny_dual", "tiny_sr", "tiny_vanilla"])
+def test_c_net_feature_lists_and_logvar(name):
+    """The rest of NVPrecond.forward's protocol behind the C ABI (training/models.py:664-670, 685-688): `return_features` as caller-visible
+    NCHW tensors (vh_net_features), `inject_features` (vh_net_run_inject: the encoder's own list, an edited list, the zero list) and
+    the logvar head (vh_net_logvar) - each equal to vivid_amd.NVPrecond, bit for bit."""
+    case = CASES[name]
+    dual = not case.get("snapshot", False)
+    py, cn = _pair(case["cfg"], case["seed"], dual)
+    inp = {k: v.cuda() for k, v in make_inputs(case).items()}
+    sigma = case["sigmas"][0]
+    sig = torch.full((inp["src"].shape[0],), float(sigma), device="cuda")
+    x = x_for(inp, sigma)
+    fa = py(inp["src"], x, sig, inp["geometry"], inp.get("cond"), return_features=True)
+    fb = cn.features(inp["src"], sig, inp["geometry"])
+    assert len(fa) == len(fb) == len(cn.feature_shapes()) > 0
+    for u, v in zip(fa, fb):
+        assert u.shape == v.shape and torch.equal(u.contiguous(), v)
+    whole = cn(inp["src"], x, sig, inp["geometry"], inp.get("cond"))
+    assert torch.equal(cn.run_inject(inp["src"], x, sig, inp["geometry"], fb, inp.get("cond")), whole)
+    for edit in (lambda f: f * 0.5, torch.zeros_like):
+        fl = [edit(f) for f in fb]
+        a = py(inp["src"], x, sig, inp["geometry"], inp.get("cond"), inject_features=fl)
+        b = cn.run_inject(inp["src"], x, sig, inp["geometry"], fl, inp.get("cond"))
+        torch.cuda.synchronize()
+        assert torch.equal(a, b) and not torch.equal(b, whole)
+    _, lv = py(inp["src"], x, sig, inp["geometry"], inp.get("cond"), return_logvar=True)
+    assert torch.equal(lv, cn.logvar(sig))
+
+
+def _torch_schedule(num_steps, sigma_min=0.002, sigma_max=80, rho=7):
+    idx = torch.arange(num_steps, dtype=torch.float32)
+    t = (sigma_max ** (1 / rho) + idx / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    return torch.cat([t, torch.zeros_like(t[:1])])
+
+
+@pytest.mark.parametrize("name,extra,noisy", [("tiny_guided", {}, 0.0), ("tiny_nte", {}, 0.0), ("tiny_sr", {}, 0.0), ("tiny_sr", {"num_steps": 3}, 0.25),
+                                              ("tiny_dual", {"num_steps": 4, "S_churn": 2.0}, 0.0), ("tiny_guided", {"num_steps": 5, "pipeline": False}, 0.0)])
+def test_c_sampler_equals_python_sampler(name, extra, noisy):
+    """vh_edm_sampler (generate_images.py:43-118 behind the C ABI) against vivid_amd.edm_sampler: guided (two nets, the guidance net on a
+    second stream), no_time_enc with churn (features once; churn noise through the caller's randn), the SR net without and WITH its
+    per-call conditioning noise, churn on a dual-source net (no two calls share a level), and the plain whole-evaluation call pattern.
+    Same kernels, same order, same draws: the samples are EQUAL.  The library's own schedule arithmetic (no t_steps given) lands within
+    an ulp of torch's levels: the samples then agree to 1e-5."""
+    import vivid_amd
+    from vivid_amd.cnet import CNet
+    case = CASES[name]
+    cfg = case["cfg"] if not case["cfg"].super_res else vivid_amd.NetConfig(**{**case["cfg"].to_dict(), "noisy_sr": noisy})
+    sd = vivid_amd.synth_state_dict(cfg, seed=case["seed"])
+    py = vivid_amd.NVPrecond.from_config(cfg, precision="bf16x3")
+    py.load_state_dict(sd, strict=True)
+    py = py.cuda()
+    cn = CNet(cfg)
+    cn.load_state_dict(sd)
+    gpy = gcn = None
+    if "gcfg" in case:
+        gsd = vivid_amd.synth_state_dict(case["gcfg"], seed=case["seed"] + 1)
+        gpy = vivid_amd.NVPrecond.from_config(case["gcfg"], precision="bf16x3")
+        gpy.load_state_dict(gsd, strict=True)
+        gpy = gpy.cuda()
+        gcn = CNet(case["gcfg"])
+        gcn.load_state_dict(gsd)
+    inp = {k: v.cuda() for k, v in make_inputs(case).items()}
+    kw = {**case["sampler"], **extra}
+    pipeline = kw.pop("pipeline", True)
+    if not pipeline:
+        os.environ["VIVID_FEATURE_PIPELINE"] = "0"
+    try:
+        torch.manual_seed(3)
+        want = vivid_amd.edm_sampler(py, inp["src"], inp["noise"], labels=inp["geometry"], gnet=gpy if gpy is not None else py,
+                                     conditioning_image=inp.get("cond"), randn_like=make_randn_like(case["seed"]), **kw)
+    finally:
+        os.environ.pop("VIVID_FEATURE_PIPELINE", None)
+    churn_rl = make_randn_like(case["seed"])
+    rows_elems = inp["noise"].numel()
+
+    def randn(n):      # churn noise (the whole state) from the test's repeatable CPU stream, conditioning noise from torch's CUDA generator - as the Python path
+        if n == rows_elems and kw.get("S_churn", 0) > 0:
+            return churn_rl(torch.empty(n, device="cuda"))
+        return torch.randn(n, device="cuda")
+    torch.manual_seed(3)
+    got = cn.edm_sampler(inp["src"], inp["noise"], labels=inp["geometry"], gnet=gcn, conditioning_image=inp.get("cond"), randn=randn,
+                         t_steps=_torch_schedule(kw["num_steps"]), pipeline=pipeline, **kw)
+    assert got.shape == want.shape and torch.equal(got, want), (name, rel_l2(got.cpu(), want.cpu()))
+    if not noisy:
+        churn_rl = make_randn_like(case["seed"])
+        own = cn.edm_sampler(inp["src"], inp["noise"], labels=inp["geometry"], gnet=gcn, conditioning_image=inp.get("cond"), randn=randn,
+                             pipeline=pipeline, **kw)
+        assert rel_l2(own.cpu(), want.cpu()) < 1e-5

@@ -147,6 +147,14 @@ class ResizeArgs(C.Structure):
                 ("ch_scale", C.c_void_p), ("ch_bias", C.c_void_p), ("channels", C.c_int)]
 
 
+class LayoutArgs(C.Structure):
+    _fields_ = [("inp", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int), ("c", C.c_int), ("hw", C.c_int), ("to_nchw", C.c_int)]
+
+
+class AxpyArgs(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("s", C.c_float), ("out", C.c_void_p), ("n", C.c_size_t)]
+
+
 class SamplerStepArgs(C.Structure):
     _fields_ = [("x_hat", C.c_void_p), ("x_probe", C.c_void_p), ("d_cond", C.c_void_p), ("d_ref", C.c_void_p),
                 ("guidance", C.c_float), ("d_cur", C.c_void_p), ("t_hat", C.c_float), ("t_next", C.c_float),
@@ -162,7 +170,17 @@ class NetConfigC(C.Structure):
                 ("label_balance", C.c_double), ("concat_balance", C.c_double), ("res_balance", C.c_double), ("attn_balance", C.c_double),
                 ("clip_act", C.c_double), ("sigma_data", C.c_double), ("logvar_channels", C.c_int),
                 ("super_res", C.c_int), ("no_time_enc", C.c_int), ("depth_input", C.c_int), ("warp_depth_coor", C.c_int), ("uncond", C.c_int),
-                ("dual_source", C.c_int), ("geom_mean", C.c_float * 20), ("geom_std", C.c_float * 20)]
+                ("dual_source", C.c_int), ("geom_mean", C.c_float * 20), ("geom_std", C.c_float * 20), ("noisy_sr", C.c_double)]
+
+
+RANDN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)        # vh_randn_fn(user, device_dst, n, stream)
+
+
+class SamplerConfigC(C.Structure):
+    """vh_sampler_config"""
+    _fields_ = [("num_steps", C.c_int), ("sigma_min", C.c_double), ("sigma_max", C.c_double), ("rho", C.c_double), ("guidance", C.c_double),
+                ("S_churn", C.c_double), ("S_min", C.c_double), ("S_max", C.c_double), ("S_noise", C.c_double), ("t_steps", C.POINTER(C.c_float)),
+                ("randn", RANDN_FN), ("randn_user", C.c_void_p), ("guidance_overlap", C.c_int)]
 
 
 # every symbol include/vivid_hip.h declares: name -> (args struct or None)
@@ -174,6 +192,7 @@ OPS = {
     "vh_warp_features": WarpArgs, "vh_sampler_step": SamplerStepArgs, "vh_codec": CodecArgs, "vh_add_depth": AddDepthArgs,
     "vh_resize_bilinear": ResizeArgs, "vh_resize": ResizeArgs,
     "vh_nonzero_flag": NonzeroArgs, "vh_resample": ResampleArgs, "vh_moments": MomentsArgs, "vh_psnr_sum": PsnrArgs,
+    "vh_layout": LayoutArgs, "vh_axpy": AxpyArgs,
 }
 TAGS = ["conv3x3", "conv1x1", "attention", "pixnorm", "qkv_split", "embed", "assemble", "sampler", "prep", "warp", "split"]
 CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", "vh_ctx_destroy", "vh_ctx_set_stream", "vh_set_knob", "vh_conv_takes_patch",
@@ -182,7 +201,9 @@ CONTROL = ["vh_abi_version", "vh_diag_flags", "vh_last_error", "vh_ctx_create", 
 
 NET = ["vh_net_create", "vh_net_destroy", "vh_net_num_params", "vh_net_param_info", "vh_net_bind_param", "vh_net_prepared_bytes",
        "vh_net_prepare", "vh_net_workspace_bytes", "vh_net_record", "vh_net_run",
-       "vh_net_workspace_bytes_mode", "vh_net_record_mode", "vh_net_encode", "vh_net_run_bound"]
+       "vh_net_workspace_bytes_mode", "vh_net_record_mode", "vh_net_encode", "vh_net_run_bound",
+       "vh_net_num_features", "vh_net_feature_shape", "vh_net_features", "vh_net_run_inject", "vh_net_logvar",
+       "vh_edm_sampler_workspace_bytes", "vh_edm_sampler"]
 
 _lib = None
 
@@ -239,12 +260,20 @@ def lib():
     L.vh_net_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
     L.vh_net_workspace_bytes.restype = C.c_size_t
     L.vh_net_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
-    L.vh_net_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+    L.vh_net_run.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
     L.vh_net_workspace_bytes_mode.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.vh_net_workspace_bytes_mode.restype = C.c_size_t
     L.vh_net_record_mode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     L.vh_net_encode.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 3
-    L.vh_net_run_bound.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6
+    L.vh_net_run_bound.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7
+    L.vh_net_num_features.argtypes = [C.c_void_p]
+    L.vh_net_feature_shape.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.vh_net_features.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+    L.vh_net_run_inject.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.POINTER(C.c_void_p), C.c_void_p]
+    L.vh_net_logvar.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.vh_edm_sampler_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
+    L.vh_edm_sampler_workspace_bytes.restype = C.c_size_t
+    L.vh_edm_sampler.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(SamplerConfigC), C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
     _lib = L
     return L
 

@@ -146,7 +146,64 @@ __global__ void psnr_fold_k(const double* per_image, int images, double* acc) {
     }
 }
 
+// ---------------------------------------------------------------- NHWC <-> NCHW (fp32), 32 x 32 tiles through LDS
+// per row (image): in [hw][c] -> out [c][hw] (to_nchw) or the other way round; both sides coalesced
+__global__ __launch_bounds__(256) void layout_k(vh_layout_args a, int tiles_a, int tiles_b) {
+    __shared__ float tile[32][33];
+    // A = the input's slow axis, B = its fast axis: to_nchw reads [hw][c] (A = hw, B = c), else [c][hw] (A = c, B = hw)
+    const int nA = a.to_nchw ? a.hw : a.c, nB = a.to_nchw ? a.c : a.hw;
+    const int t = blockIdx.x % (tiles_a * tiles_b), row = blockIdx.x / (tiles_a * tiles_b);
+    const int ta = t / tiles_b, tb = t - ta * tiles_b;
+    const float* in = a.in + (size_t)row * a.hw * a.c;
+    float* out = a.out + (size_t)row * a.hw * a.c;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ia = ta * 32 + ly + 8 * k, ib = tb * 32 + lx;
+        if (ia < nA && ib < nB) tile[ly + 8 * k][lx] = in[(size_t)ia * nB + ib];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ib = tb * 32 + ly + 8 * k, ia = ta * 32 + lx;
+        if (ia < nA && ib < nB) out[(size_t)ib * nA + ia] = tile[lx][ly + 8 * k];
+    }
+}
+
+// out = a + s * b with two roundings (torch's `a + s * b` is a multiply kernel and an add kernel); a == NULL: s * b; b == NULL: the constant s
+__global__ __launch_bounds__(256) void axpy_k(vh_axpy_args a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    float v = a.b ? __fmul_rn(a.s, a.b[i]) : a.s;
+    if (a.a) v = __fadd_rn(a.a[i], v);
+    a.out[i] = v;
+}
+
 }  // namespace
+
+extern "C" int vh_layout(vh_ctx* ctx, const vh_layout_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_layout: null args");
+    const vh_layout_args a = *p;
+    VH_REQUIRE(a.in && a.out && a.in != a.out, "vh_layout: null tensor (or in == out)");
+    VH_REQUIRE(a.rows > 0 && a.c > 0 && a.hw > 0, "vh_layout: bad geometry");
+    const int nA = a.to_nchw ? a.hw : a.c, nB = a.to_nchw ? a.c : a.hw;
+    const int tiles_a = (nA + 31) / 32, tiles_b = (nB + 31) / 32;
+    VH_REQUIRE((long long)a.rows * tiles_a * tiles_b < (1LL << 31), "vh_layout: grid too large");
+    return vh_dispatch(ctx, VH_TAG_ASSEMBLE, 0.0, 8.0 * (double)a.rows * a.c * a.hw, [a, tiles_a, tiles_b](hipStream_t s) -> int {
+        hipLaunchKernelGGL(layout_k, dim3((unsigned)(a.rows * tiles_a * tiles_b)), dim3(256), 0, s, a, tiles_a, tiles_b);
+        return vh_check_launch("layout_k");
+    });
+}
+
+extern "C" int vh_axpy(vh_ctx* ctx, const vh_axpy_args* p) {
+    if (!p) return vh_fail(VH_EINVAL, "vh_axpy: null args");
+    const vh_axpy_args a = *p;
+    VH_REQUIRE(a.out && a.n > 0, "vh_axpy: null output");
+    return vh_dispatch(ctx, VH_TAG_SAMPLER, 0.0, 4.0 * (double)a.n * (1 + (a.a ? 1 : 0) + (a.b ? 1 : 0)), [a](hipStream_t s) -> int {
+        hipLaunchKernelGGL(axpy_k, dim3(blocks_for((long long)a.n, 256)), dim3(256), 0, s, a);
+        return vh_check_launch("axpy_k");
+    });
+}
 
 extern "C" int vh_resample(vh_ctx* ctx, const vh_resample_args* p) {
     if (!p) return vh_fail(VH_EINVAL, "vh_resample: null args");

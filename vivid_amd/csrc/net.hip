@@ -163,6 +163,7 @@ struct Program {
     float* feat_base = nullptr;       // VH_NET_BOUND: workspace base of the VH_NET_FEATURES program whose buffers this plan reads in place
     Buf sigma, geometry, src, x, cond, D;
     std::vector<FeatBuf> feats;       // VH_NET_FEATURES: the encoder's feature list, (fp32, S8) pairs inside this program's workspace
+    std::vector<Buf> feats_in;        // VH_NET_INJECT: NHWC input buffers of the caller's feature list
     long long peak_floats = 0;
 };
 
@@ -186,6 +187,9 @@ struct vh_net {
     // walk state
     Arena* A = nullptr; float* base = nullptr; bool emit = false; int rc = VH_OK;
     std::map<int, CatState> cat;          // by decoder block index, for the network being walked
+    // vh_edm_sampler: streams / events of its scheduling (created on first use, destroyed with the net)
+    hipStream_t side_stream = nullptr, gside_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_enc[2] = {nullptr, nullptr}, ev_g = nullptr;
 };
 
 namespace {
@@ -380,6 +384,13 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
             release(n, qkv);
         }
         release(n, r_s8);
+        Buf fs_own;
+        Feat fsplit;
+        if (use_feat && !feat->s8.ok()) {                         // an injected list comes as fp32 only: its S8 form is made here (engine._block: own = True)
+            fs_own = split(n, feat->f32, 1.f, nullptr, 1.f, (long long)rows * nsrc * R * R, rows * nsrc, R, R, VH_PRO_NONE, false).first;
+            fsplit.f32 = feat->f32; fsplit.s8 = fs_own;
+            feat = &fsplit;
+        }
         if (use_feat) {
             if (fused) {
                 vh_qkv_epilogue e2{}; e2.q = nullptr; e2.k = ptr(n, k); e2.v = ptr(n, v); e2.heads = b.heads; e2.nj = 2; e2.rows_per_b = nsrc; e2.koff = S; e2.kl = kl; e2.qscale = 1.f;
@@ -392,6 +403,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
                 call(n, vh_qkv_split_x3, sa);
                 release(n, kv);
             }
+            release(n, fs_own);
         }
         Buf att = alloc(n, rows, R, R, C);
         vh_attention_args aa{}; aa.q = ptr(n, q); aa.k = ptr(n, k); aa.v = ptr(n, v); aa.b = rows; aa.heads = b.heads; aa.s = S; aa.kl = kl; aa.d = D;
@@ -526,7 +538,7 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
     const vh_net_config& cfg = n->cfg;
     const int R = cfg.img_resolution, nsrc = cfg.dual_source ? 2 : 1, rm = nsrc, rows_all = B * rm;
     const int src_c = 3 + ((cfg.depth_input || cfg.warp_depth_coor) ? 1 : 0);
-    const bool need_enc = n->has_enc && mode != VH_NET_BOUND, need_unet = mode != VH_NET_FEATURES;
+    const bool need_enc = n->has_enc && mode != VH_NET_BOUND && mode != VH_NET_INJECT, need_unet = mode != VH_NET_FEATURES;
     pr.mode = mode;
     pr.sigma = alloc(n, rows_all, 1, 1, 1);
     pr.geometry = alloc(n, rows_all, 1, 1, cfg.source_label_dim);
@@ -535,6 +547,12 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
         pr.x = alloc(n, rows_all, cfg.img_channels, R, R);
         pr.D = alloc(n, B, cfg.img_channels, R, R);
         if (cfg.super_res) pr.cond = alloc(n, B, cfg.img_channels, R, R);
+    }
+    std::vector<Feat> inj;
+    if (mode == VH_NET_INJECT) {                                  // inject_features :664-665: the caller's list, copied into these NHWC buffers per call
+        for (int g = 0; g < 2; ++g)
+            for (const Block& b : (g ? n->unet.dec : n->unet.enc))
+                if (!b.conv && b.xattn) { Buf f = alloc(n, rows_all, b.res, b.res, b.cout); pr.feats_in.push_back(f); Feat ft; ft.f32 = f; inj.push_back(ft); }
     }
     Buf sgrid, dgrid;
     if (cfg.warp_depth_coor) {                                    // depth-warp Fourier features :643-652
@@ -566,8 +584,8 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
     release(n, sgrid);
     if (mode == VH_NET_FEATURES) pr.feats = feats;
     if (need_unet) {
-        const bool have_feats = need_enc || ext != nullptr;
-        const std::vector<Feat>* use = ext ? ext : &feats;
+        const bool have_feats = need_enc || ext != nullptr || mode == VH_NET_INJECT;
+        const std::vector<Feat>* use = mode == VH_NET_INJECT ? &inj : ext ? ext : &feats;
         n->scratch = n->scratch_unet;
         vh_segment segs[3]; int ns = 0;
         segs[ns++] = vh_segment{ptr(n, pr.x), 0, cfg.img_channels, cfg.img_channels, rm, 1};
@@ -650,6 +668,7 @@ void layout(vh_net* n) {
             }
         if (sp.out_channels) add(prefix + "out_conv.weight", 9, 0, 0, true);
     }
+    add("logvar_linear.weight", 1, 0, 0, false);                  // the logvar head :685-688 (vh_net_logvar)
     n->prepared_floats = cur + biggest + 64;
 }
 
@@ -783,8 +802,8 @@ extern "C" int vh_net_prepare(vh_net* n, void* buffer, size_t bytes) {
 
 static int net_build(vh_net* n, int mode, int slot, int B, float* workspace, size_t bytes, Program** out) {
     VH_REQUIRE(B > 0, "vh_net: batch must be positive");
-    VH_REQUIRE(mode >= VH_NET_FULL && mode <= VH_NET_BOUND && (slot == 0 || slot == 1), "vh_net: bad mode / slot");
-    VH_REQUIRE(mode == VH_NET_FULL || n->has_enc, "vh_net: an uncond net has no encoder: only VH_NET_FULL");
+    VH_REQUIRE(mode >= VH_NET_FULL && mode <= VH_NET_INJECT && (slot == 0 || slot == 1), "vh_net: bad mode / slot");
+    VH_REQUIRE(mode == VH_NET_FULL || mode == VH_NET_INJECT || n->has_enc, "vh_net: an uncond net has no encoder: only VH_NET_FULL / VH_NET_INJECT");
     VH_REQUIRE(n->prepared || !workspace, "vh_net_record: call vh_net_prepare after binding the parameters");
     auto pr = std::make_unique<Program>();
     pr->B = B;
@@ -867,7 +886,8 @@ extern "C" int vh_net_record(vh_net* n, int batch, void* workspace, size_t bytes
 // One evaluation: D = net(src, x, sigma, geometry, cond).  All pointers are device fp32, contiguous, in the reference's layouts:
 // src [rows][3 or 4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim] (NULL for an uncond net: zeros),
 // cond [B][3][R][R] (super_res only), out [B][3][R][R]; rows = B * (dual_source ? 2 : 1).
-static int net_run(vh_net* n, int mode, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+static int net_run(vh_net* n, int mode, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+                   const float* cond_noise, const float* const* feats_in, float* out) {
     auto it = n->programs.find(std::make_tuple(mode, slot, batch));
     VH_REQUIRE(it != n->programs.end() && it->second->plan, "vh_net: no program recorded for mode %d, slot %d, batch %d (vh_net_record / vh_net_record_mode)", mode, slot, batch);
     Program& p = *it->second;
@@ -886,11 +906,25 @@ static int net_run(vh_net* n, int mode, int slot, int batch, const float* src, c
     };
     VH_REQUIRE(!p.src.ok() || src, "vh_net_run: this program reads src");
     VH_REQUIRE(!p.cond.ok() || cond, "vh_net_run: a super_res net needs the conditioning image (training/models.py:656)");
+    const bool noisy = p.cond.ok() && n->cfg.noisy_sr != 0.0;
+    VH_REQUIRE(!noisy || cond_noise, "vh_net_run: this super_res net has noisy_sr = %g: pass cond_noise, [batch][3][R][R] standard-normal draws (training/models.py:658)", n->cfg.noisy_sr);
     VH_REQUIRE(geometry || n->cfg.uncond, "vh_net_run: geometry is required for a conditional net (training/models.py:631)");
     VH_REQUIRE(!p.x.ok() || (x && out), "vh_net_run: x / out missing");
+    VH_REQUIRE(p.feats_in.empty() || feats_in, "vh_net_run_inject: feature list missing");
     int rc;
     if ((rc = put(p.sigma, sigma)) != VH_OK || (rc = put(p.geometry, geometry)) != VH_OK || (rc = put(p.src, src)) != VH_OK ||
-        (rc = put(p.x, x)) != VH_OK || (rc = put(p.cond, cond)) != VH_OK) return rc;
+        (rc = put(p.x, x)) != VH_OK) return rc;
+    if (noisy) {                                                   // cond + noisy_sr * eps, rounded like torch's two kernels (:658)
+        vh_axpy_args ax{cond, cond_noise, (float)n->cfg.noisy_sr, p.base + p.cond.off, (size_t)p.cond.n};
+        if ((rc = vh_axpy(n->ctx, &ax)) != VH_OK) return rc;
+    } else if ((rc = put(p.cond, cond)) != VH_OK) return rc;
+    for (size_t i = 0; i < p.feats_in.size(); ++i) {               // NCHW list -> the program's NHWC buffers (copied per call, like the reference's deepcopy :665)
+        const Buf& b = p.feats_in[i];
+        VH_REQUIRE(feats_in[i], "vh_net_run_inject: feature %zu is NULL", i);
+        const int rows = batch * (n->cfg.dual_source ? 2 : 1);
+        vh_layout_args la{feats_in[i], p.base + b.off, rows, b.c, (int)(b.n / ((long long)rows * b.c)), 0};
+        if ((rc = vh_layout(n->ctx, &la)) != VH_OK) return rc;
+    }
     if ((rc = vh_plan_run(n->ctx, p.plan)) != VH_OK) return rc;
     if (!p.D.ok()) return VH_OK;
     const hipError_t e = hipMemcpyAsync(out, p.base + p.D.off, (size_t)p.D.n * 4, hipMemcpyDeviceToDevice, s);
@@ -900,24 +934,268 @@ static int net_run(vh_net* n, int mode, int slot, int batch, const float* src, c
 // One evaluation: D = net(src, x, sigma, geometry, cond).  All pointers are device fp32, contiguous, in the reference's layouts:
 // src [rows][3 or 4][R][R], x [rows][3][R][R], sigma [rows], geometry [rows][source_label_dim] (NULL for an uncond net: zeros),
 // cond [B][3][R][R] (super_res only), out [B][3][R][R]; rows = B * (dual_source ? 2 : 1).
-extern "C" int vh_net_run(vh_net* n, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+extern "C" int vh_net_run(vh_net* n, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+                          const float* cond_noise, float* out) {
     if (!n || !x || !sigma || !out) return vh_fail(VH_EINVAL, "vh_net_run: null argument");
-    return net_run(n, VH_NET_FULL, 0, batch, src, x, sigma, geometry, cond, out);
+    return net_run(n, VH_NET_FULL, 0, batch, src, x, sigma, geometry, cond, cond_noise, nullptr, out);
 }
 // The two halves of an evaluation (training/models.py:664-667 / :676-683): the encoder into feature slot `slot`, and the UNet on that slot's
 // features in place.  The encoder sees (src, sigma, geometry) only, so a sampler can run it for its next noise level on another stream
-// (vh_ctx_set_stream between the calls) and once per level instead of once per call (vivid_amd/sampler.py does exactly this from Python).
+// (vh_ctx_set_stream between the calls) and once per level instead of once per call (vh_edm_sampler does exactly this).
 extern "C" int vh_net_encode(vh_net* n, int slot, int batch, const float* src, const float* sigma, const float* geometry) {
     if (!n || !src || !sigma) return vh_fail(VH_EINVAL, "vh_net_encode: null argument");
-    return net_run(n, VH_NET_FEATURES, slot, batch, src, nullptr, sigma, geometry, nullptr, nullptr);
+    return net_run(n, VH_NET_FEATURES, slot, batch, src, nullptr, sigma, geometry, nullptr, nullptr, nullptr, nullptr);
 }
-extern "C" int vh_net_run_bound(vh_net* n, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond, float* out) {
+extern "C" int vh_net_run_bound(vh_net* n, int slot, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+                                const float* cond_noise, float* out) {
     if (!n || !x || !sigma || !out) return vh_fail(VH_EINVAL, "vh_net_run_bound: null argument");
-    return net_run(n, VH_NET_BOUND, slot, batch, src, x, sigma, geometry, cond, out);
+    return net_run(n, VH_NET_BOUND, slot, batch, src, x, sigma, geometry, cond, cond_noise, nullptr, out);
+}
+
+// ---- the rest of NVPrecond.forward's protocol: feature lists in and out, the logvar head (training/models.py:664-670, 685-688)
+extern "C" int vh_net_num_features(const vh_net* n) {
+    if (!n) return 0;
+    int c = 0;
+    for (int g = 0; g < 2; ++g) for (const Block& b : (g ? n->unet.dec : n->unet.enc)) if (!b.conv && b.xattn) ++c;
+    return c;
+}
+extern "C" int vh_net_feature_shape(const vh_net* n, int i, int* channels, int* res) {
+    if (!n || !channels || !res) return vh_fail(VH_EINVAL, "vh_net_feature_shape: null argument");
+    int c = 0;
+    for (int g = 0; g < 2; ++g)
+        for (const Block& b : (g ? n->unet.dec : n->unet.enc))
+            if (!b.conv && b.xattn) { if (c == i) { *channels = b.cout; *res = b.res; return VH_OK; } ++c; }
+    return vh_fail(VH_EINVAL, "vh_net_feature_shape: index %d out of range (%d features)", i, c);
+}
+extern "C" int vh_net_features(vh_net* n, int batch, const float* src, const float* sigma, const float* geometry, float* const* features_out) {
+    if (!n || !src || !sigma || !features_out) return vh_fail(VH_EINVAL, "vh_net_features: null argument");
+    VH_REQUIRE(n->has_enc, "vh_net_features: an uncond net has no encoder (its feature list is all zeros, training/models.py:727-736)");
+    int rc = net_run(n, VH_NET_FEATURES, 0, batch, src, nullptr, sigma, geometry, nullptr, nullptr, nullptr, nullptr);
+    if (rc != VH_OK) return rc;
+    const Program& p = *n->programs.at(std::make_tuple((int)VH_NET_FEATURES, 0, batch));
+    const int rows = batch * (n->cfg.dual_source ? 2 : 1);
+    for (size_t i = 0; i < p.feats.size(); ++i) {
+        VH_REQUIRE(features_out[i], "vh_net_features: output %zu is NULL", i);
+        const Buf& b = p.feats[i].f32;
+        vh_layout_args la{p.base + b.off, features_out[i], rows, b.c, (int)(b.n / ((long long)rows * b.c)), 1};
+        if ((rc = vh_layout(n->ctx, &la)) != VH_OK) return rc;
+    }
+    return VH_OK;
+}
+extern "C" int vh_net_run_inject(vh_net* n, int batch, const float* src, const float* x, const float* sigma, const float* geometry, const float* cond,
+                                 const float* cond_noise, const float* const* features_in, float* out) {
+    if (!n || !x || !sigma || !out || !features_in) return vh_fail(VH_EINVAL, "vh_net_run_inject: null argument");
+    return net_run(n, VH_NET_INJECT, 0, batch, src, x, sigma, geometry, cond, cond_noise, features_in, out);
+}
+extern "C" int vh_net_logvar(vh_net* n, int batch, const float* sigma, float* logvar) {
+    if (!n || !sigma || !logvar || batch <= 0) return vh_fail(VH_EINVAL, "vh_net_logvar: bad argument");
+    VH_REQUIRE(n->prepared, "vh_net_logvar: call vh_net_prepare first");
+    const Weight& wl = n->W.at("logvar_linear.weight");
+    vh_embed_args a{};
+    a.sigma = sigma; a.sigma_stride = n->cfg.dual_source ? 2 : 1; a.time_scale = 1.f; a.geometry = nullptr; a.label_dim = 0; a.geometry_scale = 0.f;
+    a.freqs = P(n, "logvar_fourier.freqs"); a.phases = P(n, "logvar_fourier.phases"); a.cnoise = n->cfg.logvar_channels;
+    a.w_noise = wl.wt; a.w_noise_kpad = wl.k_pad; a.w_label = nullptr; a.w_label_kpad = 0; a.label_balance = 0.f; a.rows = batch; a.cemb = 1; a.raw = 1; a.emb = logvar;
+    return vh_embed(n->ctx, &a);
+}
+
+// ================================================================== edm_sampler (generate_images.py:43-118) over vh_net evaluations
+// vivid_amd/sampler.py restated: same schedule arithmetic (fp32, rounded where torch rounds), same call order, same kernels
+// (vh_sampler_step, vh_axpy), same scheduling (encoder once per noise level, one level ahead on a second stream; the guidance net on a
+// third for small evaluations) - so that its samples equal vivid_amd.edm_sampler's bit for bit (tests/test_hip_net_c.py).
+namespace {
+#pragma clang fp contract(off)       // the schedule below is fp32 arithmetic with torch's roundings: no fused multiply-adds
+
+size_t align_up(size_t v) { return (v + 63) / 64 * 64; }       // in floats
+struct SamplerWs { size_t xbuf, dbuf, tt, total; };               // element counts
+SamplerWs sampler_ws(const vh_net* n, int B) {
+    const int R = n->cfg.img_resolution, rm = n->cfg.dual_source ? 2 : 1;
+    SamplerWs w;
+    w.xbuf = align_up((size_t)B * rm * 3 * R * R); w.dbuf = align_up((size_t)B * 3 * R * R); w.tt = align_up((size_t)B * rm);
+    w.total = 4 * w.xbuf + 6 * w.dbuf + 3 * w.tt;      // x_hat, x_next, x_corr, churn noise | D, ref, Dp, refp, d_cur, cond noise | tt, tt_enc[2]
+    return w;
+}
+bool has_prog(const vh_net* n, int mode, int slot, int B) {
+    auto it = n->programs.find(std::make_tuple(mode, slot, B));
+    return it != n->programs.end() && it->second->plan;
+}
+int hip_rc(hipError_t e, const char* what) { return e == hipSuccess ? VH_OK : vh_fail(VH_EHIP, "vh_edm_sampler: %s: %s", what, hipGetErrorString(e)); }
+}  // namespace
+
+extern "C" size_t vh_edm_sampler_workspace_bytes(const vh_net* n, int batch) { return (n && batch > 0) ? sampler_ws(n, batch).total * 4 : 0; }
+
+extern "C" int vh_edm_sampler(vh_net* net, vh_net* gnet, const vh_sampler_config* cp, int B, const float* src, const float* noise, const float* labels,
+                              const float* cond, void* workspace, size_t workspace_bytes, float* out) {
+    if (!net || !cp || !src || !noise || !workspace || !out || B <= 0) return vh_fail(VH_EINVAL, "vh_edm_sampler: null argument");
+    const vh_sampler_config c = *cp;
+    const vh_net_config& nc = net->cfg;
+    VH_REQUIRE(c.num_steps >= 2, "vh_edm_sampler: num_steps must be >= 2 (the schedule divides by num_steps - 1, generate_images.py:69)");
+    const bool guided = c.guidance != 1.0 && gnet != nullptr;
+    VH_REQUIRE(c.guidance == 1.0 || gnet, "vh_edm_sampler: guidance != 1 needs a guidance net");
+    const SamplerWs W = sampler_ws(net, B);
+    VH_REQUIRE(workspace_bytes >= W.total * 4 && vh_aligned16(workspace), "vh_edm_sampler: workspace too small (%zu < %zu bytes) or unaligned", workspace_bytes, W.total * 4);
+    const int R = nc.img_resolution, rm = nc.dual_source ? 2 : 1, rows = B * rm, N = c.num_steps;
+    const size_t xn = (size_t)rows * 3 * R * R, dn = (size_t)B * 3 * R * R;
+    const bool churn_any = c.S_churn > 0.0;
+    const bool sr_noise = nc.super_res && nc.noisy_sr != 0.0;
+    VH_REQUIRE(!(churn_any || sr_noise) || c.randn, "vh_edm_sampler: S_churn > 0 / a super_res net with noisy_sr != 0 draw noise: give vh_sampler_config.randn");
+    VH_REQUIRE(!nc.super_res || cond, "vh_edm_sampler: a super_res net needs the conditioning image");
+    float* base = static_cast<float*>(workspace);
+    float* X[3] = {base, base + W.xbuf, base + 2 * W.xbuf};
+    float* eps = base + 3 * W.xbuf;
+    float* Dd = eps + W.xbuf; float* Rf = Dd + W.dbuf; float* Dp = Rf + W.dbuf; float* Rp = Dp + W.dbuf; float* dcur = Rp + W.dbuf; float* cn = dcur + W.dbuf;
+    float* tt = cn + W.dbuf; float* tte[2] = {tt + W.tt, tt + 2 * W.tt};
+    vh_ctx* ctx = net->ctx;
+    const hipStream_t main_s = ctx->stream;
+    int rc;
+
+    // ---- noise levels (:68-70), in fp32 like the reference (and vivid_amd/sampler.py:165-167)
+    std::vector<float> t(N + 1);
+    if (c.t_steps) { for (int i = 0; i <= N; ++i) t[i] = c.t_steps[i]; }
+    else {
+        const float a = (float)std::pow(c.sigma_max, 1.0 / c.rho), d = (float)(std::pow(c.sigma_min, 1.0 / c.rho) - std::pow(c.sigma_max, 1.0 / c.rho));
+        for (int i = 0; i < N; ++i) {
+            const float frac = (float)i / (float)(N - 1);
+            const float prod = frac * d;
+            const float v = a + prod;
+            t[i] = powf(v, (float)c.rho);
+        }
+        t[N] = 0.f;
+    }
+    // per step: churned level t_hat (:78-84) and the noise level of every denoiser call in call order (Euler call at t_hat, Heun probe at t_next)
+    const float gamma = (float)std::min(c.S_churn / N, std::sqrt(2.0) - 1.0);
+    std::vector<float> that(N), levels;
+    std::vector<char> churned(N);
+    for (int i = 0; i < N; ++i) {
+        churned[i] = churn_any && c.S_min <= (double)t[i] && (double)t[i] <= c.S_max;
+        if (churned[i]) { const float gp = gamma * t[i]; that[i] = t[i] + gp; } else that[i] = t[i];
+        levels.push_back(that[i]);
+        if (i < N - 1) levels.push_back(t[i + 1]);
+    }
+
+    // ---- which programs carry the net's calls
+    const bool split_ok = !nc.uncond && has_prog(net, VH_NET_FEATURES, 0, B) && has_prog(net, VH_NET_BOUND, 0, B);
+    const bool nte = nc.no_time_enc != 0 && split_ok;                                                   // :52-53: features once, re-used by every call
+    const bool pipe = !nc.no_time_enc && split_ok && has_prog(net, VH_NET_FEATURES, 1, B) && has_prog(net, VH_NET_BOUND, 1, B);
+    VH_REQUIRE(nte || pipe || has_prog(net, VH_NET_FULL, 0, B), "vh_edm_sampler: record VH_NET_FULL (or VH_NET_FEATURES + VH_NET_BOUND of both slots) for batch %d first", B);
+    VH_REQUIRE(!guided || has_prog(gnet, VH_NET_FULL, 0, B), "vh_edm_sampler: record the guidance net's VH_NET_FULL program for batch %d first", B);
+    bool overlap = guided && gnet != net && (c.guidance_overlap > 0 || (c.guidance_overlap < 0 && (long long)rows * R * R <= 32LL * 2 * 64 * 64));
+    if ((pipe || overlap) && !net->ev_main) {
+        if ((rc = hip_rc(hipStreamCreateWithFlags(&net->side_stream, hipStreamNonBlocking), "stream")) != VH_OK) return rc;
+        if ((rc = hip_rc(hipStreamCreateWithFlags(&net->gside_stream, hipStreamNonBlocking), "stream")) != VH_OK) return rc;
+        for (hipEvent_t* e : {&net->ev_main, &net->ev_enc[0], &net->ev_enc[1], &net->ev_g})
+            if ((rc = hip_rc(hipEventCreateWithFlags(e, hipEventDisableTiming), "event")) != VH_OK) return rc;
+    }
+    auto fill = [&](float* dst, float v, size_t n_) { vh_axpy_args a{nullptr, nullptr, v, dst, n_}; return vh_axpy(ctx, &a); };
+
+    // ---- encoder features for the sequence of levels (vivid_amd.sampler._FeaturePipeline)
+    int cur_slot = -1, ahead_slot = -1, next_slot = 0; float cur_level = 0.f, ahead_level = 0.f; bool have_cur = false, have_ahead = false;
+    auto launch_enc = [&](float level, int* slot_out) -> int {
+        int r;
+        if ((r = hip_rc(hipEventRecord(net->ev_main, main_s), "record")) != VH_OK) return r;           // everything enqueued so far, incl. the UNet call still reading this slot
+        if ((r = hip_rc(hipStreamWaitEvent(net->side_stream, net->ev_main, 0), "wait")) != VH_OK) return r;
+        const int slot = next_slot; next_slot ^= 1;
+        ctx->stream = net->side_stream;
+        r = fill(tte[slot], level, (size_t)rows);
+        if (r == VH_OK) r = net_run(net, VH_NET_FEATURES, slot, B, src, nullptr, tte[slot], labels, nullptr, nullptr, nullptr, nullptr);
+        ctx->stream = main_s;
+        if (r != VH_OK) return r;
+        if ((r = hip_rc(hipEventRecord(net->ev_enc[slot], net->side_stream), "record")) != VH_OK) return r;
+        *slot_out = slot;
+        return VH_OK;
+    };
+    auto features_for = [&](size_t k, int* slot_out) -> int {
+        const float level = levels[k];
+        int r;
+        if (!have_cur || cur_level != level) {
+            int slot;
+            if (have_ahead && ahead_level == level) slot = ahead_slot;
+            else if ((r = launch_enc(level, &slot)) != VH_OK) return r;
+            if ((r = hip_rc(hipStreamWaitEvent(main_s, net->ev_enc[slot], 0), "wait")) != VH_OK) return r;
+            cur_slot = slot; cur_level = level; have_cur = true; have_ahead = false;
+        }
+        if (!have_ahead)
+            for (size_t j = k + 1; j < levels.size(); ++j)
+                if (levels[j] != level) { if ((r = launch_enc(levels[j], &ahead_slot)) != VH_OK) return r; ahead_level = levels[j]; have_ahead = true; break; }
+        *slot_out = cur_slot;
+        return VH_OK;
+    };
+    if (nte) {      // features = net(src, 0, ones, labels, cond, return_features=True) once (:52-53); the encoder ignores sigma (time_scale 0)
+        if ((rc = fill(tte[0], 1.f, (size_t)rows)) != VH_OK) return rc;
+        if ((rc = net_run(net, VH_NET_FEATURES, 0, B, src, nullptr, tte[0], labels, nullptr, nullptr, nullptr, nullptr)) != VH_OK) return rc;
+    }
+
+    // ---- the `denoise` closure (:55-62): D = net(src, x, t, labels, cond, features), ref = gnet(src, x, t)
+    size_t call_k = 0;
+    auto denoise = [&](const float* x, float level, float* D_out, float* ref_out) -> int {
+        int r;
+        if ((r = fill(tt, level, (size_t)rows)) != VH_OK) return r;
+        int slot = 0;
+        if (pipe && (r = features_for(call_k, &slot)) != VH_OK) return r;
+        ++call_k;
+        if (guided && overlap) {
+            if ((r = hip_rc(hipEventRecord(net->ev_main, main_s), "record")) != VH_OK) return r;       // x and tt were produced on the main stream
+            if ((r = hip_rc(hipStreamWaitEvent(net->gside_stream, net->ev_main, 0), "wait")) != VH_OK) return r;
+            vh_ctx* gc = gnet->ctx; const hipStream_t gs = gc->stream;
+            gc->stream = net->gside_stream;
+            r = net_run(gnet, VH_NET_FULL, 0, B, src, x, tt, nullptr, nullptr, nullptr, nullptr, ref_out);
+            gc->stream = gs;
+            if (r != VH_OK) return r;
+            if ((r = hip_rc(hipEventRecord(net->ev_g, net->gside_stream), "record")) != VH_OK) return r;
+        }
+        const float* cnp = nullptr;
+        if (sr_noise) { c.randn(c.randn_user, cn, dn, (void*)main_s); cnp = cn; }
+        if (pipe || nte) r = net_run(net, VH_NET_BOUND, slot, B, src, x, tt, labels, cond, cnp, nullptr, D_out);
+        else r = net_run(net, VH_NET_FULL, 0, B, src, x, tt, labels, cond, cnp, nullptr, D_out);
+        if (r != VH_OK) return r;
+        if (guided && overlap) return hip_rc(hipStreamWaitEvent(main_s, net->ev_g, 0), "wait");
+        if (guided) {
+            vh_ctx* gc = gnet->ctx; const hipStream_t gs = gc->stream;
+            gc->stream = main_s;
+            r = net_run(gnet, VH_NET_FULL, 0, B, src, x, tt, nullptr, nullptr, nullptr, nullptr, ref_out);
+            gc->stream = gs;
+        }
+        return r;
+    };
+    auto step = [&](const float* x_hat, const float* x_probe, const float* D, const float* ref, float th, float tn, float* x_next) -> int {
+        vh_sampler_step_args a{};
+        a.x_hat = x_hat; a.x_probe = x_probe; a.d_cond = D; a.d_ref = guided ? ref : nullptr; a.guidance = (float)c.guidance; a.d_cur = dcur;
+        a.t_hat = th; a.t_next = tn; a.rows = B; a.row_mul = rm; a.row_elems = (size_t)3 * R * R; a.x_next = x_next;
+        return vh_sampler_step(ctx, &a);
+    };
+
+    // ---- main loop (:72-114)
+    int ix = 0;                                                    // X[ix] holds x_cur
+    { vh_axpy_args a{nullptr, noise, t[0], X[ix], xn}; if ((rc = vh_axpy(ctx, &a)) != VH_OK) return rc; }       // x0 = noise * t0
+    for (int i = 0; i < N; ++i) {
+        const float t_cur = t[i], t_next = t[i + 1], t_hat = that[i];
+        float* x_hat = X[ix];
+        if (churned[i]) {                                          // x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) * S_noise * eps, in place (:81)
+            const float th2 = t_hat * t_hat, tc2 = t_cur * t_cur;
+            const float df = th2 - tc2;
+            const float sq = sqrtf(df);
+            c.randn(c.randn_user, eps, xn, (void*)main_s);
+            vh_axpy_args a{x_hat, eps, (float)((double)sq * c.S_noise), x_hat, xn};
+            if ((rc = vh_axpy(ctx, &a)) != VH_OK) return rc;
+        }
+        float* x_nx = X[(ix + 1) % 3];
+        if ((rc = denoise(x_hat, t_hat, Dd, Rf)) != VH_OK) return rc;
+        if ((rc = step(x_hat, nullptr, Dd, Rf, t_hat, t_next, x_nx)) != VH_OK) return rc;                      // Euler (:93-98)
+        if (i < N - 1) {                                                                                       // Heun correction (:104-111)
+            float* x_co = X[(ix + 2) % 3];
+            if ((rc = denoise(x_nx, t_next, Dp, Rp)) != VH_OK) return rc;
+            if ((rc = step(x_hat, x_nx, Dp, Rp, t_hat, t_next, x_co)) != VH_OK) return rc;
+            ix = (ix + 2) % 3;
+        } else ix = (ix + 1) % 3;
+    }
+    // the even rows of the final state (:116-118)
+    return hip_rc(hipMemcpy2DAsync(out, (size_t)3 * R * R * 4, X[ix], (size_t)rm * 3 * R * R * 4, (size_t)3 * R * R * 4, (size_t)B, hipMemcpyDeviceToDevice, main_s), "copy out");
 }
 
 extern "C" int vh_net_destroy(vh_net* n) {
     if (!n) return VH_OK;
+    if (n->side_stream) (void)hipStreamDestroy(n->side_stream);
+    if (n->gside_stream) (void)hipStreamDestroy(n->gside_stream);
+    for (hipEvent_t e : {n->ev_main, n->ev_enc[0], n->ev_enc[1], n->ev_g}) if (e) (void)hipEventDestroy(e);
     for (auto& kv : n->programs) if (kv.second && kv.second->plan) (void)vh_plan_destroy(kv.second->plan);
     delete n;
     return VH_OK;
