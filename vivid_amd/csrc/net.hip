@@ -153,7 +153,7 @@ struct Buf { long long off = -1; long long n = 0; int c = 0; float* abs = nullpt
 
 struct Weight { float* wt = nullptr; size_t off = 0; int cin_pad = 0, k_pad = 0, cout = 0, taps = 0, nj = 0, D = 0, fused_c1 = 0; const float* gain = nullptr; bool has_gain = false; };
 
-struct FeatBuf { Buf f32, s8; };
+struct FeatBuf { Buf f32, s8, k, v; };      // k, v: this block's cross-attention keys / values, when the VH_NET_FEATURES program computed them with the features
 // one decoder block's concat input mp_silu(mp_cat(x, skip)) (training/models.py:78-84, :174) whose halves are written by their producers (vh_s8_sink)
 struct CatState { int rows = 0, R = 0, Na = 0, Nb = 0; float sc0 = 1.f, sc1 = 1.f; bool raw = false, ok = false, x_done = false, skip_done = false; Buf cs, craw; };
 struct Program {
@@ -369,8 +369,12 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         const int kl = use_feat ? S * (1 + nsrc) : S;
         const float nz = (b.xattn && !use_feat) ? n_zero * S : 0.f;
         const int klp = round_up(kl, 64);
-        Buf q = alloc(n, rows, b.heads, S, D), k = alloc(n, rows, b.heads, klp, D), v = alloc(n, rows, b.heads, klp, D);
         const bool fused = S % 32 == 0;
+        // the cross keys / values of this block were written when the features were (VH_NET_FEATURES: they depend on the features only,
+        // training/models.py:279-297); attn_qkv adds the self keys at offset 0 of the same tensors
+        const bool kv_pre = use_feat && feat->k.ok() && fused;
+        Buf q = alloc(n, rows, b.heads, S, D), k, v;
+        if (kv_pre) { k = feat->k; v = feat->v; } else { k = alloc(n, rows, b.heads, klp, D); v = alloc(n, rows, b.heads, klp, D); }
         const float qscale = (float)(LOG2E / std::sqrt((double)D));
         if (fused) {
             vh_qkv_epilogue e{}; e.q = ptr(n, q); e.k = ptr(n, k); e.v = ptr(n, v); e.heads = b.heads; e.nj = 3; e.rows_per_b = 1; e.koff = 0; e.kl = kl; e.qscale = qscale;
@@ -386,12 +390,12 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         release(n, r_s8);
         Buf fs_own;
         Feat fsplit;
-        if (use_feat && !feat->s8.ok()) {                         // an injected list comes as fp32 only: its S8 form is made here (engine._block: own = True)
+        if (use_feat && !kv_pre && !feat->s8.ok()) {                         // an injected list comes as fp32 only: its S8 form is made here (engine._block: own = True)
             fs_own = split(n, feat->f32, 1.f, nullptr, 1.f, (long long)rows * nsrc * R * R, rows * nsrc, R, R, VH_PRO_NONE, false).first;
             fsplit.f32 = feat->f32; fsplit.s8 = fs_own;
             feat = &fsplit;
         }
-        if (use_feat) {
+        if (use_feat && !kv_pre) {
             if (fused) {
                 vh_qkv_epilogue e2{}; e2.q = nullptr; e2.k = ptr(n, k); e2.v = ptr(n, v); e2.heads = b.heads; e2.nj = 2; e2.rows_per_b = nsrc; e2.koff = S; e2.kl = kl; e2.qscale = 1.f;
                 ConvOpt ok; ok.qkv = &e2;
@@ -409,7 +413,8 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         vh_attention_args aa{}; aa.q = ptr(n, q); aa.k = ptr(n, k); aa.v = ptr(n, v); aa.b = rows; aa.heads = b.heads; aa.s = S; aa.kl = kl; aa.d = D;
         aa.n_zero_keys = nz; aa.out = ptr(n, att); aa.out_s8 = 1; aa.logit_bound = (float)(LOG2E * std::sqrt((double)D) * 1.001);
         call(n, vh_attention_x3, aa);
-        release(n, q); release(n, k); release(n, v);
+        release(n, q);
+        if (!kv_pre) { release(n, k); release(n, v); }
         float ta2, tb2; mp_sum_coeffs(cfg.attn_balance, ta2, tb2);
         ConvOpt op; op.epi = VH_EPI_MPSUM; op.res = &out; op.ta = ta2; op.tb = tb2; op.clip = clip; op.out = &out; op.also_s8 = want_s8;
         auto r2 = conv(n, att, n->W.at(p + "attn_proj.weight"), rows, R, R, op);
@@ -582,7 +587,23 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
         release(n, cvec);
     }
     release(n, sgrid);
-    if (mode == VH_NET_FEATURES) pr.feats = feats;
+    if (mode == VH_NET_FEATURES) {
+        // cross-attention K / V of every XAttnBlock of the UNet, computed with the features (engine.Engine._cross_kv)
+        size_t fi = 0;
+        for (int g = 0; g < 2; ++g)
+            for (const Block& b : (g ? n->unet.dec : n->unet.enc)) {
+                if (b.conv || !b.xattn) continue;
+                Feat& f = feats.at(fi++);
+                const int S = b.res * b.res, D = b.cout / b.heads;
+                if (S % 32 != 0 || !f.s8.ok()) continue;
+                const int kl = S * (1 + nsrc), klp = round_up(kl, 64);
+                f.k = alloc(n, B, b.heads, klp, D); f.v = alloc(n, B, b.heads, klp, D);
+                vh_qkv_epilogue e2{}; e2.q = nullptr; e2.k = ptr(n, f.k); e2.v = ptr(n, f.v); e2.heads = b.heads; e2.nj = 2; e2.rows_per_b = nsrc; e2.koff = S; e2.kl = kl; e2.qscale = 1.f;
+                ConvOpt ok; ok.qkv = &e2;
+                conv(n, f.s8, n->W.at(std::string("unet.") + (g ? "dec." : "enc.") + b.name + ".x_attn_kv.weight"), B * nsrc, b.res, b.res, ok);
+            }
+        pr.feats = feats;
+    }
     if (need_unet) {
         const bool have_feats = need_enc || ext != nullptr || mode == VH_NET_INJECT;
         const std::vector<Feat>* use = mode == VH_NET_INJECT ? &inj : ext ? ext : &feats;
@@ -817,6 +838,7 @@ static int net_build(vh_net* n, int mode, int slot, int B, float* workspace, siz
                 Feat g = f;
                 g.f32.abs = it->second->base + f.f32.off;
                 if (g.s8.ok()) g.s8.abs = it->second->base + f.s8.off;
+                if (g.k.ok()) { g.k.abs = it->second->base + f.k.off; g.v.abs = it->second->base + f.v.off; }
                 ext.push_back(g);
             }
         } else {

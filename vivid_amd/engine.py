@@ -146,6 +146,8 @@ class Engine:
         #  the C-level walk vh_net_* reads, so the two walks stay identical.)
         self.fuse_concat = int(os.environ["VIVID_FUSE_CONCAT"]) if "VIVID_FUSE_CONCAT" in os.environ else None
         self._cat: Dict[int, dict] = {}
+        # sampler's split evaluation: cross-attention K / V computed with the features (once per noise level) instead of in every UNet call
+        self.hoist_kv = os.environ.get("VIVID_HOIST_KV", "1") != "0"
         self.cfg = cfg
         self.std_filter = tuple(float(v) for v in cfg.resample_filter) == (1.0, 1.0)
         self.dual = dual_source
@@ -482,7 +484,8 @@ class Engine:
     def _block(self, prefix: str, grp: str, b: BlockSpec, rows: int, x: Buf, skip: Optional[Buf],
                cvec_all: Buf, cols: Dict[str, int], total_cols: int,
                feat: Optional[Buf], feat_s8: Optional[Buf], n_zero: float, want_s8: bool = False,
-               cat_j: Optional[int] = None, out_sink: Optional[Tuple[int, str]] = None, fp32_optional: bool = False):
+               cat_j: Optional[int] = None, out_sink: Optional[Tuple[int, str]] = None, fp32_optional: bool = False,
+               kv_pre: Optional[Tuple[Buf, Buf]] = None):
         """Block.forward :165-206 / XAttnBlock.forward :251-315.  x is the block input (before
         resampling); returns (block output fp32, its S8 copy or None).  Neither x nor skip is released here.
         In bf16x3 mode every conv reads an S8 (bf16 hi/lo) tensor written by the op that produced it."""
@@ -616,8 +619,14 @@ class Engine:
             klp = _round_up(kl, 64) if ax3 else kl            # bf16x3: K as S8, V transposed, keys padded to 64
             split_op, attn_op = ("vh_qkv_split_x3", "vh_attention_x3") if ax3 else ("vh_qkv_split", "vh_attention")
             q = self._alloc(rows, b.heads, S, D)
-            k = self._alloc(rows, b.heads, klp, D)
-            v = self._alloc(rows, b.heads, klp, D)
+            if kv_pre is not None:
+                # the cross keys / values of this block were written when the features were (the 'features' program of this slot: they depend
+                # on the features only, training/models.py:279-297); attn_qkv adds the self keys at offset 0 of the same tensors
+                assert use_feat and fused
+                k, v = kv_pre
+            else:
+                k = self._alloc(rows, b.heads, klp, D)
+                v = self._alloc(rows, b.heads, klp, D)
             if fused:
                 self._conv([(r_s8, 1.0)], self.W[p + "attn_qkv.weight"], rows, R, R, prec=1,
                            qkv=L.QkvEpilogue(q=q.ptr, k=k.ptr, v=v.ptr, heads=b.heads, nj=3, rows_per_b=1, koff=0, kl=kl,
@@ -632,7 +641,7 @@ class Engine:
                 self._call(split_op, L.QkvSplitArgs(inp=qkv.ptr, rows=rows, s=S, heads=b.heads, d=D, nj=3, rows_per_b=1,
                                                     koff=0, kl=kl, qscale=LOG2E / math.sqrt(D), q=q.ptr, k=k.ptr, v=v.ptr))
                 self._free(qkv)
-            if use_feat:
+            if use_feat and kv_pre is None:
                 if ax3:
                     fs, own = feat_s8, False
                     if fs is None:
@@ -657,7 +666,9 @@ class Engine:
                                                 n_zero_keys=nz, out=att.ptr, out_s8=1 if ax3 else 0,
                                                 logit_bound=LOG2E * math.sqrt(D) * 1.001),   # q, k are RMS-normalised head vectors
                        f"b={rows} h={b.heads} S={S} KL={kl} D={D} nz={nz} x3={int(ax3)}")
-            self._free(q); self._free(k); self._free(v)
+            self._free(q)
+            if kv_pre is None:
+                self._free(k); self._free(v)
             ta2, tb2 = self._mp_sum_coeffs(cfg.attn_balance)
             emit = want_s8 and ax3
             r2 = self._conv([(att, 1.0)], self.W[p + "attn_proj.weight"], rows, R, R, epi=L_EPI_MPSUM, res=out,
@@ -716,10 +727,10 @@ class Engine:
 
         def next_feat(b):
             nonlocal fi
-            f = (None, None)
+            f = (None, None, None)
             if b.xattn:
                 if feats is not None:
-                    f = feats[fi]
+                    f = tuple(feats[fi]) + (None,) * (3 - len(feats[fi]))
                 fi += 1
             return f
 
@@ -734,9 +745,9 @@ class Engine:
                 self._tap(f"{prefix}enc.{b.name}.out", nx)
                 self._free(x)
             else:
-                f32, f8 = next_feat(b)
+                f32, f8, fkv = next_feat(b)
                 nx, nx8 = self._block(prefix, "enc", b, rows, x, None, cvec, cols, total, f32, f8, n_zero,
-                                      want_s8=collect and b.heads > 0, out_sink=skip_sink(ei))
+                                      want_s8=collect and b.heads > 0, out_sink=skip_sink(ei), kv_pre=fkv)
                 if collect and b.heads > 0:
                     out_feats.append((nx, nx8))
                 # x was the output of entry ei-1; if its skip half already sits in its consumer's concat tensors, this block was its last fp32 reader
@@ -750,13 +761,13 @@ class Engine:
             if not b.live:
                 break
             skip = skips.pop() if b.takes_skip else None
-            f32, f8 = next_feat(b)
+            f32, f8, fkv = next_feat(b)
             # this block's result is the x half of the NEXT block's concat input, and nothing else reads it
             nb_ = spec.dec[j + 1] if j + 1 < len(spec.dec) and spec.dec[j + 1].live else None
             xs_ok = nb_ is not None and nb_.takes_skip and (j + 1) in self._cat and self._cat[j + 1]["ok"] and not b.heads
             nx, nx8 = self._block(prefix, "dec", b, rows, x, skip, cvec, cols, total, f32, f8, n_zero,
                                   want_s8=collect and b.heads > 0, cat_j=j if j in self._cat else None,
-                                  out_sink=(j + 1, "x") if xs_ok else None, fp32_optional=xs_ok)
+                                  out_sink=(j + 1, "x") if xs_ok else None, fp32_optional=xs_ok, kv_pre=fkv)
             for old in (x, skip):
                 if old is not None and not kept(old) and all(old is not s_ for s_ in skips):
                     self._free(old)
@@ -890,6 +901,8 @@ class Engine:
                 self._free(last)
             self._free(cvec)
             io["features_out"] = [f[0] for f in feats]
+            if mode == "features" and self.hoist_kv:
+                feats = self._cross_kv(feats, B)
             io["features_pairs"] = list(feats)
         self._free(sgrid)
 
@@ -929,6 +942,32 @@ class Engine:
                     label_balance=0.0, rows=B, cemb=1, raw=1, emb=io["logvar"].ptr))
         self._free(dgrid)
         return io
+
+    def _cross_kv(self, feats, B: int):
+        """The cross-attention keys / values of every XAttnBlock of the UNet (x_attn_kv + normalize, training/models.py:279-293) depend on
+        the encoder features only - not on x, not on the UNet's own embedding - and the sampler evaluates the features once per noise level:
+        compute them HERE, in the 'features' program, into per-block K / V tensors that stay in its workspace; the 'bound' program's attn_qkv
+        adds the self keys at offset 0 and the attention reads them.  (The reference recomputes them in every UNet call, :491-492, :279-297.)
+        Returns the feature list as (fp32, S8, (K, V) or None) triples."""
+        out = []
+        blocks = [("enc", b) for b in self.unet_spec.enc] + [("dec", b) for b in self.unet_spec.dec]
+        xb = [(g, b) for g, b in blocks if b.kind == "block" and b.xattn]
+        assert len(xb) == len(feats)
+        for (g, b), (f32, f8) in zip(xb, feats):
+            C_, D = b.cout, b.cout // b.heads
+            ok = self.x3 and b.cout % 32 == 0 and b.cin % 32 == 0 and D in (32, 64) and self._qkv_fused(b) and f8 is not None
+            if not ok:
+                out.append((f32, f8, None))
+                continue
+            S, R = b.res * b.res, b.res
+            kl = S * (1 + self.nsrc)
+            klp = _round_up(kl, 64)
+            k = self._alloc(B, b.heads, klp, D)
+            v = self._alloc(B, b.heads, klp, D)
+            self._conv([(f8, 1.0)], self.W[f"unet.{g}.{b.name}.x_attn_kv.weight"], B * self.nsrc, R, R, prec=1,
+                       qkv=L.QkvEpilogue(q=None, k=k.ptr, v=v.ptr, heads=b.heads, nj=2, rows_per_b=self.nsrc, koff=S, kl=kl, qscale=1.0))
+            out.append((f32, f8, (k, v)))
+        return out
 
     def _feature_shapes(self):
         return [(b.cout, b.res) for b in self.unet_spec.enc + self.unet_spec.dec if b.kind == "block" and b.xattn]
