@@ -21,5 +21,11 @@ python3 tools/op_profile.py --res 256 --batch 16 > profiles/${TAG%%_c2*}_layers_
 python3 tools/op_profile.py --res 256 --batch 16 --uncond > profiles/${TAG%%_c2*}_layers_c2_gnet.txt 2>/dev/null
 python3 tools/op_profile.py --res 1024 --batch 4 --sr > profiles/${TAG%%_c2*}_layers_c4_sr1024_b4.txt 2>/dev/null
 python3 tools/op_profile.py --res 256 --batch 16 --warp > profiles/${TAG%%_c2*}_layers_c5_warp.txt 2>/dev/null
-rm -rf gpurun_out/profiles_new && mkdir -p gpurun_out/profiles_new && cp profiles/${TAG}* profiles/${TAG%%_c2*}_layers_* gpurun_out/profiles_new/
+python3 - <<PY
+import json
+d = json.load(open("profiles/$TAG.json"))
+json.dump({"source": "profiles/$TAG.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of \`bench.py --steps 2 --no-extras\`, library built from the commit the file was committed with)",
+           "families": d["families"]}, open("profiles/traffic_c2_bf16x3.json", "w"))
+PY
+rm -rf gpurun_out/profiles_new && mkdir -p gpurun_out/profiles_new && cp profiles/${TAG}* profiles/${TAG%%_c2*}_layers_* profiles/traffic_c2_bf16x3.json gpurun_out/profiles_new/
 tail -30 $OUT/summary.txt

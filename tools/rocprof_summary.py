@@ -14,10 +14,10 @@ import os
 import re
 
 FAMILIES = [("conv_igemm_f32<9>", "conv3x3"), ("conv_igemm_f32<1>", "conv1x1"), ("conv_igemm<9", "conv3x3"),
-            ("conv_igemm<1", "conv1x1"), ("conv_x3_glds<9", "conv3x3"), ("conv_x3_glds<1", "conv1x1"), ("attn_fwd", "attention"),
+            ("conv_igemm<1", "conv1x1"), ("conv_x3_glds<9", "conv3x3"), ("conv_x3_glds<1", "conv1x1"), ("conv_x3_patch", "conv3x3"), ("attn_fwd", "attention"),
             ("pixnorm_k", "pixnorm"), ("qkv_split_k", "qkv_split"), ("embed_k", "embed"), ("linear_k", "embed"),
             ("assemble_k", "assemble"), ("precond_out_k", "assemble"), ("sampler_step_k", "sampler"),
-            ("prep_weight_k", "prep"), ("warp_features_k", "warp"), ("split_k", "split")]
+            ("prep_weight_k", "prep"), ("warp_features_k", "warp"), ("split_k", "split"), ("layout_k", "assemble"), ("axpy_k", "sampler")]
 
 
 def short(name):
