@@ -173,7 +173,7 @@ def test_conv_glds_random_shapes(ctx, rows, h, w, cin, cout, taps, epi, up):
 
 @pytest.mark.parametrize("epi", [0, 1, 2])
 @pytest.mark.parametrize("korder", [1, 2])                  # VH_KORDER_TAP, VH_KORDER_CHUNK
-@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32), (7, 192), (7, 96), (7, 384), (8, 64)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU), 256x192 (+ ragged N, two N-tiles), the patch-resident kernel (16x16-pixel tiles hanging over both image edges)
+@pytest.mark.parametrize("tile,cout", [(1, 256), (2, 256), (3, 256), (3, 96), (4, 64), (5, 64), (5, 32), (7, 192), (7, 96), (7, 384), (8, 64), (8, 128), (8, 192), (8, 256)])   # 256x128, 256x256, 512x128 (+ ragged N), 512x64, 256x64 (two per CU), 256x192 (+ ragged N, two N-tiles), the patch-resident kernel (16x16-pixel tiles hanging over both image edges; 64-, 128- and 96-channel blocks, two N blocks)
 def test_conv_glds_korder_tile_sweep(ctx, tile, cout, korder, epi):
     """Every workgroup tile of conv_x3_glds with both K orders and every epilogue, forced through vh_conv_args.tile / .korder on a
     small ragged problem, against the oracle's mp_conv (the wide tile with chunk-major K is what the headline 128x128 layers run;

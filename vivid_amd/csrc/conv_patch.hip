@@ -151,13 +151,14 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
 // shrinks from 2.0 to 0.45 us (s_memtime stamps), worth +3 % with two chunks (64 input channels: one boundary, short K loop) and -2.5 %
 // with four or six (the extra LDS traffic and the address work sit in a K loop that is MFMA-paced while both workgroups of the CU are in
 // theirs): the launcher takes it for cin_pad <= 64 only.
-// NJ: 16-channel N tiles per wave - 4 (Cout <= 64) or 8 (Cout <= 128: 64 accumulator registers, 16 KB weight stages, 73 KB of LDS).
+// NJ: 16-channel N tiles per wave - 4 (Cout <= 64), 8 (128 channels per workgroup: 64 accumulator registers, 16 KB weight stages, 73 KB of LDS) or
+// 6 (96: Cout = 192 as two blocks, where 128-channel blocks would leave the second half empty).
 template <int NJ, bool TAIL, bool PF>
 __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
-    static_assert(NJ == 4 || NJ == 8, "64 or 128 output channels per workgroup");
-    static_assert(!(TAIL && NJ == 8), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
-    static_assert(!(PF && NJ == 8), "the landing pad of the next chunk's pieces and 32 KB of weight stages do not fit half a CU's LDS");
-    constexpr int BN = NJ * 16, RB = BN / 64;                // output channels per workgroup; weight DMA pieces per wave and K-tile
+    static_assert(NJ == 4 || NJ == 6 || NJ == 8, "64, 96 or 128 output channels per workgroup");
+    static_assert(!(TAIL && NJ > 4), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
+    static_assert(!(PF && NJ > 4), "the landing pad of the next chunk's pieces and 32 KB of weight stages do not fit half a CU's LDS");
+    constexpr int BN = NJ * 16, RB = (BN + 63) / 64;         // output channels per workgroup; weight DMA pieces per wave and K-tile (stage = RB * 64 rows)
     // One LDS region for activations: the resident patch (PSLOTS 16-byte slots, 41 KB) and, behind it, the landing pad of the next chunk's
     // LDS-DMA pieces (PF); the TAIL variant re-uses the whole region as two 32 KB stages of its 1-tap segment (80 KB with the
     // weights: exactly half a CU's LDS) - and the epilogue as eight per-wave transpose patches.
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     constexpr int ASLOTS = TAIL ? 4096 : PSLOTS + (PF ? XSLOTS : 0);
     static_assert(PSLOTS + XSLOTS <= 4096, "landing pad must fit behind the patch");
     __shared__ float4 sA[ASLOTS];
-    __shared__ float4 sB[2][BN * 8];                         // weight K-tiles, two stages (16 / 32 KB)
+    __shared__ float4 sB[2][RB * 64 * 8];                    // weight K-tiles, two stages (16 / 32 KB)
     float4* const sP = sA;
     float4* const sX = sA + PSLOTS;
     (void)sX;
@@ -234,12 +235,12 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     const float4* pbB[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int gnB = nb * BN + j * 64 + w * 8 + (l >> 3);
-        pbB[j] = gnB >= a.cout ? nullptr : a.wt + (size_t)gnB * KU + uB;
+        const int rloc = j * 64 + w * 8 + (l >> 3), gnB = nb * BN + rloc;
+        pbB[j] = (rloc >= BN || gnB >= a.cout) ? nullptr : a.wt + (size_t)gnB * KU + uB;
     }
     auto issueB = [&](int st, int ku) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < RB; ++j) glds16p(pbB[j] ? pbB[j] + ku : zp, ldsB_w + (unsigned)st * (unsigned)(BN * 128) + j * 8192u);
+        for (int j = 0; j < RB; ++j) glds16p(pbB[j] ? pbB[j] + ku : zp, ldsB_w + (unsigned)st * (unsigned)(RB * 8192) + j * 8192u);
     };
 
     f32x4 acc[2][NJ];
@@ -431,8 +432,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     auto run = [&](auto epic) __attribute__((always_inline)) {
         constexpr int EPI = decltype(epic)::value;
         const int cb = nb * BN;                                // first output channel of this workgroup
-        if constexpr (NJ == 4) {
-            // the residual / cvec values of block 1 are requested before block 0 is written out
+        if constexpr (NJ < 8) {
+            // the residual / cvec values of block b + 1 are requested before block b is written out
             PAux cur = patch_prefetch<EPI>(a, img, yb, x0, cb, le);
 #pragma unroll
             for (int ni = 0; ni < NJ / 2; ++ni) {
@@ -472,11 +473,14 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
     k.pty = (k.h + PT - 1) / PT;
     k.div_ptx = vhconv::fastdiv_make((unsigned)k.ptx);
     k.div_ptiles = vhconv::fastdiv_make((unsigned)(k.ptx * k.pty));
-    const bool wide = k.cout > 64 && k.c1 == 0;                // 128 output channels per workgroup (no tail instantiation: see the kernel)
-    k.NT = (k.cout + (wide ? 127 : 63)) / (wide ? 128 : 64);
+    const bool wide = k.cout > 64 && k.c1 == 0;                // 128 (or 96) output channels per workgroup (no tail instantiation: see the kernel)
+    const bool n96 = wide && k.cout % 96 == 0 && k.cout % 128 != 0;
+    const int bn = n96 ? 96 : wide ? 128 : 64;
+    k.NT = (k.cout + bn - 1) / bn;
     const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty * k.NT);
     const bool pf = k.cin_pad <= 64;
-    if (wide) hipLaunchKernelGGL((conv_x3_patch<8, false, false>), dim3(grid), dim3(512), 0, s, k);
+    if (n96) hipLaunchKernelGGL((conv_x3_patch<6, false, false>), dim3(grid), dim3(512), 0, s, k);
+    else if (wide) hipLaunchKernelGGL((conv_x3_patch<8, false, false>), dim3(grid), dim3(512), 0, s, k);
     else if (k.c1 > 0) { if (pf) hipLaunchKernelGGL((conv_x3_patch<4, true, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<4, true, false>), dim3(grid), dim3(512), 0, s, k); }
     else { if (pf) hipLaunchKernelGGL((conv_x3_patch<4, false, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<4, false, false>), dim3(grid), dim3(512), 0, s, k); }
 }

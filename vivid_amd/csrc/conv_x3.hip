@@ -639,7 +639,8 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
     const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
     const bool tailp = a.src1 != nullptr;
-    const long long pwgs = ptiles * ((a.cout > 64 && !tailp) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
+    const bool n96 = a.cout > 64 && !tailp && a.cout % 96 == 0 && a.cout % 128 != 0;                                // 96-channel blocks (Cout = 192)
+    const long long pwgs = ptiles * (n96 ? a.cout / 96 : (a.cout > 64 && !tailp) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
     if (pwgs_out) *pwgs_out = pwgs;
     const int pknob = vh_knob(VH_KNOB_CONV_PATCH);
     // Size rule, from same-device A/B against the tile the rules of vh_conv_x3_glds_dispatch pick (profiles/r04_ab_conv_patch_vs_glds.txt): the patch
@@ -648,7 +649,8 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     // 32 tiles), at Cout = 192 (two blocks of 128 channels, the second half empty: 0.93-0.96x against the 256x192 tile) and with a tail segment at
     // Cout >= 256 (64-channel blocks with the tail's 80 KB of LDS: 0.93-0.99x).
     const int mres = a.h < a.w ? a.h : a.w;
-    const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0) && (!tailp || a.cout <= 128) && (mres >= 64 || a.cout <= 256);
+    const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) && (!tailp || a.cout <= 128) &&
+                            (mres >= 64 || a.cout <= 256);
     return (patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))))) ? 1 : 0;
 }
 
