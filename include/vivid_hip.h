@@ -62,6 +62,7 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * "fuse_concat": whole-network walks (vh_net_*, and vivid_amd.engine through the same knob): the halves of a decoder block's concat input written by
  *   the convolutions that produce them (vh_s8_sink) - 2 both halves, 1 the x half only, 0 (default) never (a vh_split pass over the fp32 tensors);
  * "conv_patch96": 1 (default) Cout = 192 layers run the patch-resident kernel as two 96-channel blocks, 0: the 256x192 tile (A/B);
+ * "conv_patch_tail": tail segment of the patch-resident kernel - 2 (default) staged per wave through registers, 1 through two LDS-DMA stages (A/B);
  * "conv_patch_delay": start delay, in units of 2048 shader cycles, of every CU's second workgroup in the first round of a patch-kernel launch.
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);

@@ -315,7 +315,7 @@ def test_conv_s8_sinks_equal_split_of_the_result(ctx, cout, c1, epi):
 @pytest.mark.parametrize("korder", [1, 2])
 @pytest.mark.parametrize("tile,cout,c1,scratch", [(0, 96, 160, True), (0, 384, 768, True), (1, 128, 256, False), (2, 256, 96, False), (3, 128, 64, False),
                                                   (5, 64, 128, False), (5, 32, 32, False), (4, 64, 128, False), (7, 192, 384, False), (7, 96, 64, False),
-                                                  (8, 64, 128, False), (8, 64, 32, False)])
+                                                  (8, 64, 128, False), (8, 64, 32, False), (8, 128, 256, False), (8, 256, 96, False), (8, 192, 64, False)])
 def test_conv_glds_tail_segment(ctx, tile, cout, c1, scratch, korder):
     """A bf16x3 second source = 1-tap tail segment of the 3x3 K loop: conv_res1 + conv_skip of a decoder block as ONE GEMM,
         x = mp_sum(conv_skip(x_cat), conv_res1(y), t) = clip(ta * W_skip x_cat + tb * W_res1 * y)        training/models.py:184-186, 204-205

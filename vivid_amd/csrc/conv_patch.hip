@@ -153,10 +153,12 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
 // theirs): the launcher takes it for cin_pad <= 64 only.
 // NJ: 16-channel N tiles per wave - 4 (Cout <= 64), 8 (128 channels per workgroup: 64 accumulator registers, 16 KB weight stages, 73 KB of LDS) or
 // 6 (96: Cout = 192 as two blocks, where 128-channel blocks would leave the second half empty).
-template <int NJ, bool TAIL, bool PF>
+// TAIL: 0 no second source; 1 the 1-tap tail through two 32 KB LDS-DMA stages (NJ = 4 only: 80 KB with the weights); 2 through registers and a
+// wave-private 4 KB LDS area (any NJ: each wave's 32 pixels are read by that wave alone, so their staging needs no barrier and no second stage).
+template <int NJ, int TAIL, bool PF>
 __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     static_assert(NJ == 4 || NJ == 6 || NJ == 8, "64, 96 or 128 output channels per workgroup");
-    static_assert(!(TAIL && NJ > 4), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
+    static_assert(!(TAIL == 1 && NJ > 4), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
     static_assert(!(PF && NJ > 4), "the landing pad of the next chunk's pieces and 32 KB of weight stages do not fit half a CU's LDS");
     constexpr int BN = NJ * 16, RB = (BN + 63) / 64;         // output channels per workgroup; weight DMA pieces per wave and K-tile (stage = RB * 64 rows)
     // One LDS region for activations: the resident patch (PSLOTS 16-byte slots, 41 KB) and, behind it, the landing pad of the next chunk's
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     // weights: exactly half a CU's LDS) - and the epilogue as eight per-wave transpose patches.
     constexpr int PXL = 2;                                   // next chunk's pieces 0..PXL-1 (and wave 0's sixth) go through the landing pad, the rest through registers
     constexpr int XSLOTS = PXL * 512 + 64;
-    constexpr int ASLOTS = TAIL ? 4096 : PSLOTS + (PF ? XSLOTS : 0);
+    constexpr int ASLOTS = TAIL == 1 ? 4096 : PSLOTS + (PF ? XSLOTS : 0);
     static_assert(PSLOTS + XSLOTS <= 4096, "landing pad must fit behind the patch");
     __shared__ float4 sA[ASLOTS];
     __shared__ float4 sB[2][RB * 64 * 8];                    // weight K-tiles, two stages (16 / 32 KB)
@@ -232,15 +234,17 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     const int KU = a.k_pad >> 2;
     const int uslotB = (l & 7) ^ (((w & 1) << 2) | (l >> 4));
     const int uB = (uslotB & 3) * 2 + (uslotB >> 2);
-    const float4* pbB[RB];
+    unsigned pbo[RB], pbv = 0;                                 // weight row of this lane per piece: 32-bit offset from a.wt in 16-byte units (+ a valid bit): half the registers of pointers
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int rloc = j * 64 + w * 8 + (l >> 3), gnB = nb * BN + rloc;
-        pbB[j] = (rloc >= BN || gnB >= a.cout) ? nullptr : a.wt + (size_t)gnB * KU + uB;
+        const bool valid = rloc < BN && gnB < a.cout;
+        pbo[j] = valid ? (unsigned)gnB * (unsigned)KU + (unsigned)uB : 0u;
+        pbv |= valid ? (1u << j) : 0u;
     }
     auto issueB = [&](int st, int ku) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < RB; ++j) glds16p(pbB[j] ? pbB[j] + ku : zp, ldsB_w + (unsigned)st * (unsigned)(RB * 8192) + j * 8192u);
+        for (int j = 0; j < RB; ++j) glds16p(((pbv >> j) & 1u) ? a.wt + (size_t)(pbo[j] + (unsigned)ku) : zp, ldsB_w + (unsigned)st * (unsigned)(RB * 8192) + j * 8192u);
     };
 
     f32x4 acc[2][NJ];
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
     const int l15 = l & 15, kg = l >> 4;
     const int pbase0 = (2 * w + 1) * PP + l15 + 1;             // patch pixel of (tile row 2w, column l15) for the centre tap; row 2w+1 is PP further
-    const int brow16 = l15 * 8, u16h = kg ^ (l15 >> 1), u16l = (4 + kg) ^ (l15 >> 1);
+    const int brow16 = l15 * 8, u16h = kg ^ (l15 >> 1);
 
     auto mfma3 = [&](f32x4& c, const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl) __attribute__((always_inline)) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
-            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][(brow16 + j * 128 + u16h) ^ 4]);     // lo unit = hi unit ^ 4
 #pragma unroll
             for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
         }
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
     // ---- main loop: chunks of 32 channels; per chunk the patch is staged once and the nine taps run against it -------------------------
     const int nch = a.cin_pad >> 5;
-    const int ntail = TAIL ? (a.c1 >> 5) : 0;
+    const int ntail = TAIL != 0 ? (a.c1 >> 5) : 0;
 #ifdef VH_CLOCK
     PCK(ck_p1);
 #endif
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
             // weights of the next K-tile: next tap of this chunk, tap 0 of the next chunk, or the first tail tile
             if (tap < 8) issueB(st ^ 1, ((tap + 1) * a.cin_pad + c * 32) >> 2);
             else if (c + 1 < nch) issueB(st ^ 1, ((c + 1) * 32) >> 2);
-            else if (TAIL && ntail > 0) issueB(st ^ 1, (9 * a.cin_pad) >> 2);
+            else if (TAIL != 0 && ntail > 0) issueB(st ^ 1, (9 * a.cin_pad) >> 2);
             const bool pf = PF && tap == 0 && c + 1 < nch;
             if (pf) {
                 // plain loads, behind this K-tile's weight DMA in the wave's (in-order) memory queue: the tile waits for all but these
@@ -361,7 +365,64 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
             st ^= 1;
         }
     }
-    if constexpr (TAIL) {
+    if constexpr (TAIL == 2) {
+        // 1-tap tail over the second source, wave-private: a wave's 32 pixels x 32 channels (4 KB) are fetched by that wave itself - coalesced, 8 lanes
+        // per 128-byte pixel line, one K-tile ahead into registers - written to its own corner of the (now free) patch space and read back as MFMA
+        // fragments: the LDS pass is only the lane transpose, there is nothing to publish, so the A path needs no barrier and no second stage
+        // (the weights keep their two shared stages and the per-K-tile barrier).
+        if (ntail > 0) {
+            // (lane coordinates re-derived from the hardware counter: carried across the main loop they cost it a register it does not have at NJ = 8)
+            const int lt = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), l15t = lt & 15, kgt = lt >> 4;
+            const int brow16t = l15t * 8, u16ht = kgt ^ (l15t >> 1);
+            const float4* s14 = reinterpret_cast<const float4*>(a.src1);
+            const unsigned c14 = (unsigned)(a.c1 >> 2);
+            f32x4 nx[4];
+            // piece j of this lane: pixel q = (lane>>3) + 8j of the wave's 32 (tile row 2w + (q>>4), column q & 15), LDS unit lane & 7.  Its source is
+            // recomputed per K-tile from an opaque copy of the lane id (cf. piece_src): five registers the NJ = 8 loop does not have
+            auto fetchA = [&](unsigned cu) __attribute__((always_inline)) {
+                int lq = lt;
+                asm volatile("" : "+v"(lq));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = (lq >> 3) + 8 * j, up = lq & 7;
+                    const int yy = y0 + 2 * w + (q >> 4), xx = x0 + (q & 15);
+                    const bool inside = yy < a.h && xx < a.w;
+                    const int u = up ^ (q & 7), s8u = (u & 3) * 2 + (u >> 2);
+                    nx[j] = *reinterpret_cast<const f32x4*>(inside ? s14 + (size_t)((img_off + (unsigned)(yy * a.w + xx)) * c14 + (unsigned)s8u + cu) : zp);
+                }
+            };
+            fetchA(0u);
+            float4* const mine = sA + w * 256;                                // this wave's [32 pixels][8 units], swizzled q & 7 like the patch
+            for (int c = 0; c < ntail; ++c) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(&mine[j * 64 + lt]) = nx[j];      // slot (q, up) = q * 8 + up = j * 64 + l
+                if (c + 1 < ntail) {
+                    issueB(st ^ 1, (9 * a.cin_pad + (c + 1) * 32) >> 2);
+                    fetchA((unsigned)(c + 1) * 8u);
+                }
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = i * 16 + l15t;
+                    const int ih = q * 8 + (kgt ^ (q & 7));
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&mine[ih]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&mine[ih ^ 4]);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16t + j * 128 + u16ht]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][(brow16t + j * 128 + u16ht) ^ 4]);     // lo unit = hi unit ^ 4
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
+                }
+                if (c + 1 < ntail) wait_dma_but<4>();                        // the next weight tile has landed; the four fragment loads behind it stay in flight
+                else wait_dma_p();
+                __syncthreads();
+                st ^= 1;
+            }
+        }
+    }
+    if constexpr (TAIL == 1) {
         // 1-tap tail over the second source (c1 channels, same 256 pixels, no halo): conv_x3_glds' loop - per K-tile a 256-row x 32-channel
         // A tile (row r = tile pixel (r>>4, r&15), swizzle r&7) and a weight tile staged by LDS-DMA into the stage not being read.
         if (ntail > 0) {
@@ -402,7 +463,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) {
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16h]);
-                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][brow16 + j * 128 + u16l]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][(brow16 + j * 128 + u16h) ^ 4]);     // lo unit = hi unit ^ 4
 #pragma unroll
                     for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
                 }
@@ -473,14 +534,22 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
     k.pty = (k.h + PT - 1) / PT;
     k.div_ptx = vhconv::fastdiv_make((unsigned)k.ptx);
     k.div_ptiles = vhconv::fastdiv_make((unsigned)(k.ptx * k.pty));
-    const bool wide = k.cout > 64 && k.c1 == 0;                // 128 (or 96) output channels per workgroup (no tail instantiation: see the kernel)
+    // 128 (or 96) output channels per workgroup beyond 64; with a tail segment the wave-private form (TAIL = 2) serves every block width,
+    // knob "conv_patch_tail": 2 (default) always, 1 the LDS-DMA staged tail where it exists (64-channel blocks)
+    const int tmode = k.c1 > 0 ? (vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1 ? 1 : 2) : 0;
+    const bool wide = k.cout > 64 && tmode != 1;
     const bool n96 = wide && k.cout % 96 == 0 && k.cout % 128 != 0;
     const int bn = n96 ? 96 : wide ? 128 : 64;
     k.NT = (k.cout + bn - 1) / bn;
     const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty * k.NT);
-    const bool pf = k.cin_pad <= 64;
-    if (n96) hipLaunchKernelGGL((conv_x3_patch<6, false, false>), dim3(grid), dim3(512), 0, s, k);
-    else if (wide) hipLaunchKernelGGL((conv_x3_patch<8, false, false>), dim3(grid), dim3(512), 0, s, k);
-    else if (k.c1 > 0) { if (pf) hipLaunchKernelGGL((conv_x3_patch<4, true, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<4, true, false>), dim3(grid), dim3(512), 0, s, k); }
-    else { if (pf) hipLaunchKernelGGL((conv_x3_patch<4, false, true>), dim3(grid), dim3(512), 0, s, k); else hipLaunchKernelGGL((conv_x3_patch<4, false, false>), dim3(grid), dim3(512), 0, s, k); }
+    const bool pf = k.cin_pad <= 64 && bn == 64;
+#define VH_PATCH_LAUNCH(NJ_, T_, PF_) hipLaunchKernelGGL((conv_x3_patch<NJ_, T_, PF_>), dim3(grid), dim3(512), 0, s, k)
+    if (tmode == 0) {
+        if (n96) VH_PATCH_LAUNCH(6, 0, false); else if (wide) VH_PATCH_LAUNCH(8, 0, false); else if (pf) VH_PATCH_LAUNCH(4, 0, true); else VH_PATCH_LAUNCH(4, 0, false);
+    } else if (tmode == 1) {
+        if (pf) VH_PATCH_LAUNCH(4, 1, true); else VH_PATCH_LAUNCH(4, 1, false);
+    } else {
+        if (n96) VH_PATCH_LAUNCH(6, 2, false); else if (wide) VH_PATCH_LAUNCH(8, 2, false); else if (pf) VH_PATCH_LAUNCH(4, 2, true); else VH_PATCH_LAUNCH(4, 2, false);
+    }
+#undef VH_PATCH_LAUNCH
 }

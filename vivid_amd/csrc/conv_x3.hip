@@ -639,18 +639,19 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
     const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
     const bool tailp = a.src1 != nullptr;
-    const bool n96 = a.cout > 64 && !tailp && a.cout % 96 == 0 && a.cout % 128 != 0;                                // 96-channel blocks (Cout = 192)
-    const long long pwgs = ptiles * (n96 ? a.cout / 96 : (a.cout > 64 && !tailp) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
+    const bool wide_ok = !tailp || vh_knob(VH_KNOB_CONV_PATCH_TAIL) != 1;                                           // (the staged tail exists for 64-channel blocks only)
+    const bool n96 = a.cout > 64 && wide_ok && a.cout % 96 == 0 && a.cout % 128 != 0;                               // 96-channel blocks (Cout = 192)
+    const long long pwgs = ptiles * (n96 ? a.cout / 96 : (a.cout > 64 && wide_ok) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
     if (pwgs_out) *pwgs_out = pwgs;
     const int pknob = vh_knob(VH_KNOB_CONV_PATCH);
     // Size rule, from same-device A/B against the tile the rules of vh_conv_x3_glds_dispatch pick (profiles/r04_ab_conv_patch_vs_glds.txt): the patch
     // kernel leads by +20..29 % at Cout = 64, +13..20 % at Cout = 128 (256^2 / 512^2 / 1024^2), +3..10 % at Cout = 256 / 384 down to 64^2, ties at
     // 32^2 x 512 and loses where its 16x16-pixel tiles do not fit the image (16^2: 0.6-0.87x, 8^2: 0.38x), on small grids (no split-K: 0.35-0.67x at
-    // 32 tiles), at Cout = 192 (two blocks of 128 channels, the second half empty: 0.93-0.96x against the 256x192 tile) and with a tail segment at
-    // Cout >= 256 (64-channel blocks with the tail's 80 KB of LDS: 0.93-0.99x).
+    // 32 tiles); Cout = 192 runs as two 96-channel blocks (+9..20 % over the 256x192 tile).  With a tail segment (wave-private staging, any block
+    // width): +15..24 % at Cout = 64, +11..12 % at 128, +9 % at 192, +7 % at 384, ties (1.00-1.02x) at 256 and 512, which stay on conv_x3_glds.
     const int mres = a.h < a.w ? a.h : a.w;
-    const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) && (!tailp || a.cout <= 128) &&
-                            (mres >= 64 || a.cout <= 256);
+    const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) &&
+                            (!tailp || a.cout <= 192 || (a.cout == 384 && wide_ok)) && (mres >= 64 || a.cout <= 256);
     return (patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))))) ? 1 : 0;
 }
 
