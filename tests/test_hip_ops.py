@@ -466,6 +466,24 @@ def test_conv_up_mpsum_clip(ctx, prec, KERN):
                                   ta=0.7 / n, tb=0.3 / n, clip=2.0))
     torch.cuda.synchronize()
     assert rel_l2(out.cpu(), _nhwc(ref)) < (2e-5 if prec == 0 else 1e-4)
+    if prec == 1 and KERN == 1:
+        # the same epilogue on the patch-resident kernel (VH_TILE_PATCH16), 128 channels, an image that is not a multiple of the 16-pixel tile
+        rows, h, w, c = 2, 24, 40, 128
+        xlow = torch.randn(rows, c, h // 2, w // 2, generator=g) * 3
+        y_in = torch.randn(rows, c, h, w, generator=g)
+        wgt = torch.randn(c, c, 3, 3, generator=g)
+        ref = R.mp_sum(R.resample(xlow, "up"), R.mp_conv(y_in, wgt), t=0.3).clip(-2.0, 2.0)
+        wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+        yd, rd = _nhwc(y_in).cuda(), _nhwc(xlow).cuda()
+        src = torch.empty(rows * h * w * cin_pad, device="cuda")
+        ctx.call("vh_split", L.SplitArgs(src0=yd.data_ptr(), src1=None, c0=c, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=rows * h * w, c_pad=cin_pad, out=src.data_ptr()))
+        out = torch.empty(rows, h, w, c, device="cuda")
+        ctx.call("vh_conv", L.ConvArgs(src0=src.data_ptr(), src1=None, c0=cin_pad, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0, wt=wt.data_ptr(),
+                                      cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0, cout=c, out=out.data_ptr(),
+                                      out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=2, cvec=None, cvec_ld=0, res=rd.data_ptr(), res_up=1, ta=0.7 / n, tb=0.3 / n,
+                                      clip=2.0, tile=8))
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu(), _nhwc(ref)) < 1e-4
 
 
 @pytest.mark.parametrize("pool", [0, 1])

@@ -107,7 +107,7 @@ def main():
         flops = 2.0 * M * cout * (cin * taps + c1)
         x1 = torch.randn(rows, h, w, c1, generator=g).cuda() if c1 else None
         wgt1 = torch.randn(cout, c1, 1, 1, generator=g).cuda() if c1 else None
-        res = torch.randn(M, cout, generator=g).cuda() if epi == 2 else None
+        res = torch.randn(M, cout, generator=g).cuda() if epi == 2 else None     # (knob resup=1: read as the half-resolution residual of an `up` block)
         cvec = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda() if epi == 1 else None
         heads, S = cout // 192, h * w
         for name, lib, knobs in parse_variants():
@@ -135,7 +135,7 @@ def main():
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
                            scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if (s8mode != 1 and epi != 3) else None, out_s8=o8.data_ptr() if o8 is not None else None,
                            out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,
-                           cvec=cvec.data_ptr() if cvec is not None else None, cvec_ld=cout if cvec is not None else 0, res=res.data_ptr() if res is not None else None, res_up=0, ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
+                           cvec=cvec.data_ptr() if cvec is not None else None, cvec_ld=cout if cvec is not None else 0, res=res.data_ptr() if res is not None else None, res_up=knobs.pop("resup", 0), ta=0.7, tb=0.3, clip=256.0 if epi == 2 else 0.0,
                            korder=knobs.pop("korder", 0), tile=knobs.pop("tile", 0), stagger=knobs.pop("stagger", 0),
                            qkv=ct.addressof(qkv) if qkv is not None else None)
             runs.append((name, ctx, "vh_conv", a, knobs, (s8, s81, wt, qkv, (Q, K, V) if epi == 3 else None, o8, out, o8 if s8mode == 1 else out)))   # (every buffer the launch writes stays referenced)

@@ -65,7 +65,8 @@ __device__ __forceinline__ PAux patch_prefetch(const ConvK& a, int img, int yb, 
         const int yy = yb + (i >> 1), xx = x0 + rsub + 8 * (i & 1);
         if (EPI == VH_EPI_MPSUM) {
             if (yy < a.h && xx < a.w) {
-                const size_t gm = ((size_t)img * a.h + yy) * a.w + xx;
+                // res_up: the residual is the block input of an `up` block, at half resolution, nearest-replicated (resample 'up', training/models.py:60-61)
+                const size_t gm = a.res_up ? ((size_t)img * (a.h >> 1) + (yy >> 1)) * (a.w >> 1) + (xx >> 1) : ((size_t)img * a.h + yy) * a.w + xx;
                 x.v[i] = *reinterpret_cast<const float4*>(a.res + gm * a.cout + gn);
                 x.rs[i] = a.res_scale ? a.ta * a.res_scale[gm] : a.ta;
             }

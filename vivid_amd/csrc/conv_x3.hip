@@ -633,7 +633,7 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s);      // conv_patch
 // Patch-resident kernel (conv_patch.hip): does it run these (validated) arguments?  1 yes, 0 no, -1 = VH_TILE_PATCH16 forced on ineligible ones.
 int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out) {
     // (the kernel addresses its inputs through 32-bit offsets in 16-byte units: M * c / 4 < 2^32)
-    const bool patch_ok = a.taps == 9 && !a.up && a.cout % 32 == 0 && a.epi != VH_EPI_QKV && !(a.epi == VH_EPI_MPSUM && a.res_up) &&
+    const bool patch_ok = a.taps == 9 && !a.up && a.cout % 32 == 0 && a.epi != VH_EPI_QKV &&
                           a.prec == VH_PREC_BF16X3 && a.kernel == VH_CONV_GLDS256 &&
                           (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0;
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
@@ -661,7 +661,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     {
         long long pwgs = 0;
         const int pc = vh_conv_patch_choice(a, M, &pwgs);
-        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up` / res_up, cout %% 32 == 0 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
+        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up`, cout %% 32 == 0 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
         if ((a.sink[0].ptr || a.sink[1].ptr) && pc != 1)
             return vh_fail(VH_EINVAL, "vh_conv: S8 sinks given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
         if (pc == 1) {
