@@ -37,7 +37,7 @@ extern "C" {
 typedef struct vh_ctx vh_ctx;
 typedef struct vh_plan vh_plan;
 
-#define VH_ABI_VERSION 4
+#define VH_ABI_VERSION 5
 int vh_abi_version(void);                                /* == VH_ABI_VERSION of the header the library was built from */
 const char* vh_last_error(void);
 
@@ -493,8 +493,8 @@ int vh_psnr_sum(vh_ctx* ctx, const vh_psnr_args* a);
  * architecture from the constructor arguments (UNet.__init__ :322-384, XAttnUNet :413-480, UNetEncoder trimming :524-534,
  * SRXAttnUNet :576-582), names the parameters with the reference's state_dict keys, prepares the weights once (:115-120) and
  * records the evaluation per batch size as a vh_plan over a workspace the caller owns; a call copies the inputs in, replays, and
- * copies D_x out - no allocation, no host synchronisation.  Arithmetic: bf16x3 (see VH_PREC_BF16X3) on the direct-to-LDS kernels;
- * channel counts must be multiples of 32, attention heads 64 (32 for super_res UNets) channels, resample_filter [1,1].
+ * copies D_x out - no allocation, no host synchronisation.  Arithmetic: bf16x3 (see VH_PREC_BF16X3) on the direct-to-LDS kernels -
+ * channel counts must be multiples of 32, attention heads 64 (32 for super_res UNets) channels - or exact fp32 (vh_net_config.fp32).
  * An `uncond` net has no encoder: the zero features of :727-736 enter the attention in closed form and `src` / `geometry` may be NULL.
  * vivid_amd.NVPrecond (engine.py) emits the same op sequence from Python; tests/test_hip_net_c.py compares the two bit for bit.
  *
@@ -524,6 +524,11 @@ typedef struct {
     float geom_mean[20], geom_std[20];         /* warp_depth_coor only: the geometry statistics for this image size (training/utils.py:38-44, 77-78) */
     double noisy_sr;                           /* super_res: the net sees cond + noisy_sr * N(0,1) on EVERY forward, also at inference (training/models.py:658,
                                                   0.25 in --preset=vivid-sr).  The draws are the caller's: `cond_noise` of the run calls, required while this is != 0 */
+    int resample_ntaps; float resample_filter[8];   /* Block.resample_filter (:139): 0 taps = the default [1,1] (fused into vh_pixnorm / vh_conv); any other
+                                                  even-length filter (2..8 taps, unnormalised like the reference's argument) runs vh_resample per
+                                                  up / down block */
+    int fp32;                                  /* 0: bf16x3 arithmetic (the default, the timed path).  1: exact fp32 - VH_PREC_F32 convolutions on the register-staged
+                                                  tile, vh_qkv_split / vh_attention, no S8 tensors (vivid_amd.NVPrecond(precision="fp32")); any channel count */
 } vh_net_config;
 int vh_net_create(vh_ctx* ctx, const vh_net_config* cfg, vh_net** out);
 int vh_net_destroy(vh_net* net);

@@ -18,21 +18,21 @@ from tests.golden.cases import CASES, make_inputs, make_randn_like, x_for
 pytestmark = pytest.mark.gpu
 
 
-def _pair(cfg, seed, dual=True):
+def _pair(cfg, seed, dual=True, precision="bf16x3"):
     import vivid_amd
     from vivid_amd.cnet import CNet
     if cfg.super_res:               # the SR net's conditioning noise (training/models.py:658) off on both sides; test_c_net_noisy_sr_... has it on
         cfg = vivid_amd.NetConfig(**{**cfg.to_dict(), "noisy_sr": 0.0})
     sd = vivid_amd.synth_state_dict(cfg, seed=seed)
-    py = vivid_amd.NVPrecond.from_config(cfg, dual_source=dual, precision="bf16x3")
+    py = vivid_amd.NVPrecond.from_config(cfg, dual_source=dual, precision=precision)
     py.load_state_dict(sd, strict=True)
     py.noisy_sr = 0.0
-    cn = CNet(cfg, dual_source=dual)
+    cn = CNet(cfg, dual_source=dual, precision=precision)
     cn.load_state_dict(sd)
     return py.cuda(), cn
 
 
-@pytest.mark.parametrize("name", ["tiny_dual", "tiny_sr", "tiny_warp", "tiny_warp_zero", "tiny_depth", "tiny_vanilla"])
+@pytest.mark.parametrize("name", ["tiny_dual", "tiny_sr", "tiny_warp", "tiny_warp_zero", "tiny_depth", "tiny_vanilla", "tiny_opts"])
 def test_c_net_equals_python_engine_and_golden(name, golden_dir):
     case = CASES[name]
     dual = not case.get("snapshot", False)
@@ -47,6 +47,25 @@ def test_c_net_equals_python_engine_and_golden(name, golden_dir):
         torch.cuda.synchronize()
         assert torch.equal(a, b), (name, sigma, rel_l2(b.cpu(), a.cpu()))
         assert rel_l2(b.cpu(), g[f"D_{i}"]) < 1e-4              # the reference's own D_x for this case and noise level
+
+
+@pytest.mark.parametrize("name", ["tiny_dual", "tiny_sr", "tiny_opts", "tiny_vanilla"])
+def test_c_net_fp32_mode_equals_python_engine_and_golden(name, golden_dir):
+    """vh_net_config.fp32 = 1: the exact-fp32 walk of the C net (VH_PREC_F32 convolutions, vh_qkv_split / vh_attention, mp_silu / mp_cat in the
+    loaders, no S8 tensors) against NVPrecond(precision='fp32') - equal bits - and the reference's golden D_x at the fp32 mode's tolerance."""
+    case = CASES[name]
+    dual = not case.get("snapshot", False)
+    py, cn = _pair(case["cfg"], case["seed"], dual, precision="fp32")
+    inp = {k: v.cuda() for k, v in make_inputs(case).items()}
+    g = np.load(os.path.join(golden_dir, f"{name}.npz"))
+    for i, sigma in enumerate(case["sigmas"]):
+        sig = torch.full((inp["src"].shape[0],), float(sigma), device="cuda")
+        x = x_for(inp, sigma)
+        a = py(inp["src"], x, sig, inp["geometry"], inp.get("cond"))
+        b = cn(inp["src"], x, sig, inp["geometry"], inp.get("cond"))
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (name, sigma, rel_l2(b.cpu(), a.cpu()))
+        assert rel_l2(b.cpu(), g[f"D_{i}"]) < 2e-5
 
 
 def test_c_net_uncond_guidance_net():

@@ -84,7 +84,7 @@ def test_library_is_a_product_build():
     from vivid_amd import _lib
     L = _lib.lib()
     assert L.vh_diag_flags() == 0
-    assert L.vh_abi_version() == _lib.ABI_VERSION == 4
+    assert L.vh_abi_version() == _lib.ABI_VERSION == 5
     for knob, default in (("conv_korder", -1), ("conv_stagger", -1), ("attn_pipe", 1), ("attn_nomax", 1), ("attn_xcd", 1), ("attn_m16", 1)):
         _lib.set_knob(knob, default)
     with pytest.raises(_lib.VividHipError):

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VIVID_HIP_LIB") or os.path.join(_HERE, "libvivid_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
-ABI_VERSION = 4          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
+ABI_VERSION = 5          # VH_ABI_VERSION of include/vivid_hip.h these structures mirror
 
 
 class VividHipError(RuntimeError):
@@ -170,7 +170,8 @@ class NetConfigC(C.Structure):
                 ("label_balance", C.c_double), ("concat_balance", C.c_double), ("res_balance", C.c_double), ("attn_balance", C.c_double),
                 ("clip_act", C.c_double), ("sigma_data", C.c_double), ("logvar_channels", C.c_int),
                 ("super_res", C.c_int), ("no_time_enc", C.c_int), ("depth_input", C.c_int), ("warp_depth_coor", C.c_int), ("uncond", C.c_int),
-                ("dual_source", C.c_int), ("geom_mean", C.c_float * 20), ("geom_std", C.c_float * 20), ("noisy_sr", C.c_double)]
+                ("dual_source", C.c_int), ("geom_mean", C.c_float * 20), ("geom_std", C.c_float * 20), ("noisy_sr", C.c_double),
+                ("resample_ntaps", C.c_int), ("resample_filter", C.c_float * 8), ("fp32", C.c_int)]
 
 
 RANDN_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)        # vh_randn_fn(user, device_dst, n, stream)

@@ -18,7 +18,7 @@ from .arch import NetConfig
 from .geometry import geometry_stats
 
 
-def c_config(cfg: NetConfig, dual_source: bool = True) -> L.NetConfigC:
+def c_config(cfg: NetConfig, dual_source: bool = True, precision: str = "bf16x3") -> L.NetConfigC:
     c = L.NetConfigC(img_resolution=cfg.img_resolution, img_channels=cfg.img_channels, source_label_dim=cfg.source_label_dim,
                      target_label_dim=cfg.target_label_dim, model_channels=cfg.model_channels, num_levels=len(cfg.channel_mult),
                      num_blocks=cfg.num_blocks, num_attn_resolutions=len(cfg.attn_resolutions),
@@ -36,8 +36,15 @@ def c_config(cfg: NetConfig, dual_source: bool = True) -> L.NetConfigC:
     mean, std = geometry_stats(cfg.img_resolution)
     for i in range(20):
         c.geom_mean[i], c.geom_std[i] = float(mean[i]), float(std[i])
-    if tuple(float(v) for v in cfg.resample_filter) != (1.0, 1.0):
-        raise ValueError("vh_net implements the default resample_filter [1, 1] only")
+    f = [float(v) for v in cfg.resample_filter]
+    if len(f) % 2 or not 2 <= len(f) <= 8:
+        raise ValueError(f"resample_filter must have 2, 4, 6 or 8 taps (the reference asserts an even length, training/models.py:52); got {f}")
+    c.resample_ntaps = len(f)
+    for i, v in enumerate(f):
+        c.resample_filter[i] = v
+    if precision not in ("fp32", "bf16x3"):
+        raise ValueError(f"precision must be 'fp32' or 'bf16x3', got {precision!r}")
+    c.fp32 = int(precision == "fp32")
     return c
 
 
@@ -67,12 +74,12 @@ def _hip():
 
 
 class CNet:
-    def __init__(self, cfg: NetConfig, dual_source: bool = True, stream: int = 0):
-        self.cfg, self.dual = cfg, dual_source
+    def __init__(self, cfg: NetConfig, dual_source: bool = True, stream: int = 0, precision: str = "bf16x3"):
+        self.cfg, self.dual, self.precision = cfg, dual_source, precision
         self._L = L.lib()
         self.ctx = L.Context(stream)
         h = C.c_void_p()
-        self._cfg_c = c_config(cfg, dual_source)
+        self._cfg_c = c_config(cfg, dual_source, precision)
         L.check(self._L.vh_net_create(self.ctx.handle, C.byref(self._cfg_c), C.byref(h)), "vh_net_create")
         self.handle = h
         self._keep: List[torch.Tensor] = []

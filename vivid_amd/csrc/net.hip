@@ -5,7 +5,7 @@
 // architecture tables UNet.__init__ builds (:322-384, :413-480, :524-534, :576-582).
 //
 // This is the production walk of vivid_amd/engine.py restated in C++ for hosts without Python: bf16x3 arithmetic on the
-// direct-to-LDS convolution kernels with the fused q/k/v epilogue, default [1,1] resample filter, modes "full" (encoder + UNet)
+// direct-to-LDS convolution kernels with the fused q/k/v epilogue, any even resample filter ([1,1] fused), modes "full" (encoder + UNet)
 // and "uncond" (UNet with the zero features in closed form).  It emits the SAME op sequence with the same arguments as the Python
 // engine (tests/test_hip_net_c.py compares the two outputs bit for bit), records it once per batch size into a vh_plan over a
 // caller-supplied workspace, and replays it; nothing is allocated inside a call.
@@ -183,6 +183,8 @@ struct vh_net {
     size_t prepared_floats = 0;
     float* zeros = nullptr; float* scratch_enc = nullptr; float* scratch_unet = nullptr; float* scratch = nullptr;
     bool prepared = false;
+    bool fp32 = false;            // vh_net_config.fp32: exact-fp32 arithmetic (engine.Engine(precision="fp32")) instead of bf16x3
+    bool std_filter = true; int ntaps = 2; float taps[8] = {0.5f, 0.5f};          // Block.resample_filter (:139), normalised (f / sum f, :53)
     std::map<std::tuple<int, int, int>, std::unique_ptr<Program>> programs;      // (mode, slot, batch)
     // walk state
     Arena* A = nullptr; float* base = nullptr; bool emit = false; int rc = VH_OK;
@@ -281,6 +283,16 @@ void mp_sum_coeffs(double t, float& a, float& b) { const double nn = std::sqrt((
 
 using Feat = FeatBuf;
 
+// resample() with a non-default filter (training/models.py:48-61) as its own launch (engine.Engine._resample); [1,1] is fused into
+// vh_pixnorm (down) and vh_conv (up) instead
+Buf resample(vh_net* n, const Buf& x, int rows, int h, int w, bool up) {
+    Buf out = up ? alloc(n, rows, h * 2, w * 2, x.c) : alloc(n, rows, h / 2, w / 2, x.c);
+    vh_resample_args a{}; a.in = ptr(n, x); a.out = ptr(n, out); a.rows = rows; a.h = h; a.w = w; a.c = x.c; a.up = up ? 1 : 0; a.ntaps = n->ntaps;
+    for (int i = 0; i < n->ntaps; ++i) a.taps[i] = n->taps[i];
+    call(n, vh_resample, a);
+    return out;
+}
+
 // Block.forward :165-206 / XAttnBlock.forward :251-315 (bf16x3 path of engine.Engine._block)
 std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, int rows, const Buf& x, const Buf* skip, const Buf& cvec_all,
                           const vh_net::EmbW& emb, const Feat* feat, int nsrc, float n_zero, bool want_s8, int cat_j = -1, int out_sink_j = -1, int out_sink_half = 0,
@@ -300,9 +312,13 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
     if (!b.dec) {
         Buf xs = alloc(n, rows, R, R, C), xn, res_scale;
         vh_pixnorm_args pa{}; pa.rows = rows; pa.h = R; pa.w = R; pa.c = C; pa.norm = 1; pa.out_s8 = nullptr;
-        if (b.resample == 2) {
+        if (b.resample == 2 && n->std_filter) {
             xn = alloc(n, rows, R, R, C);
             pa.in = ptr(n, x); pa.out = ptr(n, xn); pa.pool = 1; pa.out_s8 = ptr(n, xs);
+            call(n, vh_pixnorm, pa);
+        } else if (b.resample == 2) {                                  // general FIR filter (:48-59), then the plain pixel norm
+            xn = resample(n, x, rows, R * 2, R * 2, false);
+            pa.in = ptr(n, xn); pa.out = ptr(n, xn); pa.pool = 0; pa.out_s8 = ptr(n, xs);
             call(n, vh_pixnorm, pa);
         } else if (has_skip_conv) {
             auto xr = split(n, x, 1.f, nullptr, 1.f, npix, rows, R, R, VH_PRO_NONE, false);
@@ -325,7 +341,13 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         release(n, y); release(n, xn); release(n, res_scale);
         out = r.first; r_s8 = r.second;
     } else {
-        const int up = b.resample == 1 ? 1 : 0;
+        int up = b.resample == 1 ? 1 : 0;
+        Buf xup; const Buf* xp = &x;
+        if (up && !n->std_filter) {                                // general FIR filter (:60-61): materialise the upsampled input
+            xup = resample(n, x, rows, R / 2, R / 2, true);
+            xp = &xup; up = 0;
+        }
+        const Buf& x = *xp;                                       // (shadows the parameter from here on, like engine._block's `x = xup`)
         float sc0 = 1.f, sc1 = 1.f;
         if (skip) {                                               // mp_cat :78-84
             const double t = cfg.concat_balance, Na = x.c, Nb = skip->c;
@@ -359,7 +381,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
             o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
             r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
         }
-        release(n, y);
+        release(n, y); release(n, xup);
         out = r.first; r_s8 = r.second;
     }
     if (fin_s8) out_s8 = r_s8;
@@ -424,6 +446,117 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
     return {out, out_s8};
 }
 
+// ---- the exact-fp32 walk (vh_net_config.fp32; the fp32 branches of engine.Engine._conv / _block): fp32 NHWC tensors only, mp_silu / mp_cat in
+// the convolution's loader, VH_PREC_F32 on the register-staged 128x128 tile, vh_qkv_split / vh_attention - no S8 forms, no fusions
+struct ConvF {
+    const Buf* s1 = nullptr; float sc0 = 1.f, sc1 = 1.f;      // second source of a channel concat and the mp_cat weights
+    int up = 0, pro = VH_PRO_NONE, epi = VH_EPI_STORE; const float* cvec = nullptr; int cvec_ld = 0;
+    const Buf* res = nullptr; int res_up = 0; float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr;
+};
+Buf conv_f32(vh_net* n, const Buf& s0, const Weight& W, int rows, int h, int w, const ConvF& o) {
+    Buf out = o.out ? *o.out : alloc(n, rows, h, w, W.cout);
+    vh_conv_args a{};
+    a.src0 = ptr(n, s0); a.src1 = o.s1 ? ptr(n, *o.s1) : nullptr; a.c0 = s0.c; a.c1 = o.s1 ? o.s1->c : 0; a.scale0 = o.sc0; a.scale1 = o.sc1;
+    a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = o.pro;
+    a.wt = W.wt; a.cin_pad = W.cin_pad; a.k_pad = W.k_pad; a.zeros = n->zeros; a.zeros_bytes = ZEROS_FLOATS * 4; a.cout = W.cout;
+    a.scratch = n->scratch; a.scratch_floats = SCRATCH_FLOATS;
+    a.out = ptr(n, out); a.out_s8 = nullptr; a.out_s8_c = 0;
+    a.prec = VH_PREC_F32; a.kernel = VH_CONV_TILE128; a.epi = o.epi; a.cvec = o.cvec; a.cvec_ld = o.cvec_ld;
+    a.res = o.res ? ptr(n, *o.res) : nullptr; a.res_up = o.res_up; a.res_scale = nullptr; a.ta = o.ta; a.tb = o.tb; a.clip = o.clip; a.qkv = nullptr;
+    a.stagger = 0; a.korder = VH_KORDER_AUTO; a.tile = VH_TILE_AUTO;
+    call(n, vh_conv, a);
+    return out;
+}
+
+// Block.forward :165-206 / XAttnBlock.forward :251-315, fp32
+Buf block_f32(vh_net* n, const std::string& prefix, const Block& b, int rows, const Buf& x_in, const Buf* skip, const Buf& cvec_all,
+              const vh_net::EmbW& emb, const Feat* feat, int nsrc, float n_zero) {
+    const vh_net_config& cfg = n->cfg;
+    const std::string p = prefix + (b.dec ? "dec." : "enc.") + b.name + ".";
+    const int R = b.res, C = b.cout, D = b.heads ? C / b.heads : 0;
+    const float* cv = ptr(n, cvec_all) ? ptr(n, cvec_all) + emb.cols.at(p) : (const float*)nullptr;
+    if (!n->emit) cv = reinterpret_cast<const float*>(16);          // (dry walk: never dereferenced)
+    float ta, tb; mp_sum_coeffs(cfg.res_balance, ta, tb);
+    const float clip = cfg.clip_act > 0.0 ? (float)cfg.clip_act : 0.f, clip_res = b.heads ? 0.f : clip;
+    const bool has_skip_conv = b.cin != b.cout;
+    Buf out;
+    if (!b.dec) {
+        Buf xn;
+        vh_pixnorm_args pa{}; pa.rows = rows; pa.h = R; pa.w = R; pa.c = C; pa.norm = 1; pa.out_s8 = nullptr;
+        if (b.resample == 2 && n->std_filter) {
+            xn = alloc(n, rows, R, R, C);
+            pa.in = ptr(n, x_in); pa.out = ptr(n, xn); pa.pool = 1;
+        } else if (b.resample == 2) {
+            xn = resample(n, x_in, rows, R * 2, R * 2, false);
+            pa.in = ptr(n, xn); pa.out = ptr(n, xn); pa.pool = 0;
+        } else if (has_skip_conv) {
+            xn = conv_f32(n, x_in, n->W.at(p + "conv_skip.weight"), rows, R, R, ConvF{});
+            pa.in = ptr(n, xn); pa.out = ptr(n, xn); pa.pool = 0;
+        } else {
+            xn = alloc(n, rows, R, R, C);
+            pa.in = ptr(n, x_in); pa.out = ptr(n, xn); pa.pool = 0;
+        }
+        call(n, vh_pixnorm, pa);
+        ConvF o0; o0.pro = VH_PRO_SILU; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total;
+        Buf y = conv_f32(n, xn, n->W.at(p + "conv_res0.weight"), rows, R, R, o0);
+        ConvF o1; o1.epi = VH_EPI_MPSUM; o1.res = &xn; o1.ta = ta; o1.tb = tb; o1.clip = clip_res;
+        out = conv_f32(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
+        release(n, y); release(n, xn);
+    } else {
+        int up = b.resample == 1 ? 1 : 0;
+        Buf xup; const Buf* xp = &x_in;
+        if (up && !n->std_filter) { xup = resample(n, x_in, rows, R / 2, R / 2, true); xp = &xup; up = 0; }
+        const Buf& x = *xp;
+        ConvF src;                                                // the (1-2) sources every convolution of this block that reads the input shares
+        if (skip) {                                               // mp_cat :78-84
+            const double t = cfg.concat_balance, Na = x.c, Nb = skip->c;
+            const double Cc = std::sqrt((Na + Nb) / ((1 - t) * (1 - t) + t * t));
+            src.sc0 = (float)(Cc / std::sqrt(Na) * (1 - t)); src.sc1 = (float)(Cc / std::sqrt(Nb) * t); src.s1 = skip;
+        }
+        ConvF o0 = src; o0.up = up; o0.pro = VH_PRO_SILU; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total;
+        Buf y = conv_f32(n, x, n->W.at(p + "conv_res0.weight"), rows, R, R, o0);
+        Buf xsk;
+        ConvF o1; o1.epi = VH_EPI_MPSUM; o1.ta = ta; o1.tb = tb; o1.clip = clip_res;
+        if (has_skip_conv) {
+            ConvF os = src; os.up = up;
+            xsk = conv_f32(n, x, n->W.at(p + "conv_skip.weight"), rows, R, R, os);
+            o1.res = &xsk; o1.res_up = 0;
+        } else { o1.res = &x; o1.res_up = up; }
+        out = conv_f32(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
+        release(n, y); release(n, xsk); release(n, xup);
+    }
+    if (b.heads) {
+        const int S = R * R;
+        const bool use_feat = b.xattn && feat != nullptr;
+        const int kl = use_feat ? S * (1 + nsrc) : S;
+        const float nz = (b.xattn && !use_feat) ? n_zero * S : 0.f;
+        Buf q = alloc(n, rows, b.heads, S, D), k = alloc(n, rows, b.heads, kl, D), v = alloc(n, rows, b.heads, kl, D);
+        const float qscale = (float)(LOG2E / std::sqrt((double)D));
+        Buf qkv = conv_f32(n, out, n->W.at(p + "attn_qkv.weight"), rows, R, R, ConvF{});
+        vh_qkv_split_args sa{}; sa.in = ptr(n, qkv); sa.rows = rows; sa.s = S; sa.heads = b.heads; sa.d = D; sa.nj = 3; sa.rows_per_b = 1; sa.koff = 0; sa.kl = kl;
+        sa.qscale = qscale; sa.q = ptr(n, q); sa.k = ptr(n, k); sa.v = ptr(n, v);
+        call(n, vh_qkv_split, sa);
+        release(n, qkv);
+        if (use_feat) {
+            Buf kv = conv_f32(n, feat->f32, n->W.at(p + "x_attn_kv.weight"), rows * nsrc, R, R, ConvF{});
+            vh_qkv_split_args sb{}; sb.in = ptr(n, kv); sb.rows = rows * nsrc; sb.s = S; sb.heads = b.heads; sb.d = D; sb.nj = 2; sb.rows_per_b = nsrc; sb.koff = S; sb.kl = kl;
+            sb.qscale = 1.f; sb.q = nullptr; sb.k = ptr(n, k); sb.v = ptr(n, v);
+            call(n, vh_qkv_split, sb);
+            release(n, kv);
+        }
+        Buf att = alloc(n, rows, R, R, C);
+        vh_attention_args aa{}; aa.q = ptr(n, q); aa.k = ptr(n, k); aa.v = ptr(n, v); aa.b = rows; aa.heads = b.heads; aa.s = S; aa.kl = kl; aa.d = D;
+        aa.n_zero_keys = nz; aa.out = ptr(n, att); aa.out_s8 = 0; aa.logit_bound = (float)(LOG2E * std::sqrt((double)D) * 1.001);
+        call(n, vh_attention, aa);
+        release(n, q); release(n, k); release(n, v);
+        float ta2, tb2; mp_sum_coeffs(cfg.attn_balance, ta2, tb2);
+        ConvF op; op.epi = VH_EPI_MPSUM; op.res = &out; op.ta = ta2; op.tb = tb2; op.clip = clip; op.out = &out;
+        conv_f32(n, att, n->W.at(p + "attn_proj.weight"), rows, R, R, op);
+        release(n, att);
+    }
+    return out;
+}
+
 // emb = mp_silu(mp_sum(emb_noise(fourier(c_noise)), emb_label(geometry))) :388-391 and every block's emb_linear in one launch
 Buf embedding(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net::EmbW& emb, int rows, const Buf& sigma, int sigma_stride, float time_scale,
               const Buf& geometry, int label_dim) {
@@ -481,13 +614,20 @@ Buf run_unet(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net:
             cprev = b.cout;
         }
     }
-    const int fuse = vh_knob(VH_KNOB_FUSE_CONCAT);
+    const int fuse = n->fp32 ? 0 : vh_knob(VH_KNOB_FUSE_CONCAT);
     if (fuse <= 0) { n->cat.clear(); consumer.clear(); }
     auto skip_sink = [&](int ei) { auto it = consumer.find(ei); return (fuse >= 2 && it != consumer.end() && n->cat.at(it->second).ok) ? it->second : -1; };
     for (int ei = 0; ei < (int)sp.enc.size(); ++ei) {
         const Block& b = sp.enc[ei];
         Buf nx;
-        if (b.conv) {
+        if (b.conv && n->fp32) {
+            nx = conv_f32(n, x, n->W.at(prefix + "enc." + b.name + ".weight"), rows, b.res, b.res, ConvF{});
+            release(n, x);
+        } else if (n->fp32) {
+            const Feat* f = next_feat(b);
+            nx = block_f32(n, prefix, b, rows, x, nullptr, cvec, emb, f, nsrc, n_zero);
+            if (collect && b.heads > 0) out_feats->push_back(Feat{nx, Buf{}});
+        } else if (b.conv) {
             auto xs8 = split(n, x, 1.f, nullptr, 1.f, (long long)rows * b.res * b.res, rows, b.res, b.res, VH_PRO_NONE, false);
             ConvOpt oc; oc.sink_j = skip_sink(ei); oc.sink_half = 1;
             nx = conv(n, xs8.first, n->W.at(prefix + "enc." + b.name + ".weight"), rows, b.res, b.res, oc).first;
@@ -517,7 +657,8 @@ Buf run_unet(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net:
         // this block's result is the x half of the NEXT block's concat input, and nothing else reads it
         const Block* nb = (j + 1 < (int)sp.dec.size() && sp.dec[j + 1].live) ? &sp.dec[j + 1] : nullptr;
         const bool xs_ok = nb && nb->takes_skip && n->cat.count(j + 1) && n->cat.at(j + 1).ok && !b.heads;
-        auto r = block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0, n->cat.count(j) ? j : -1, xs_ok ? j + 1 : -1, 0, xs_ok);
+        auto r = n->fp32 ? std::pair<Buf, Buf>{block_f32(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero), Buf{}}
+                         : block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0, n->cat.count(j) ? j : -1, xs_ok ? j + 1 : -1, 0, xs_ok);
         if (x.ok() && !kept(x) && !in_skips(x)) release(n, x);
         if (sk && skip.ok() && !kept(skip) && !in_skips(skip) && skip.off != x.off) release(n, skip);
         if (collect && b.heads > 0) out_feats->push_back(Feat{r.first, r.second});
@@ -578,7 +719,7 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
         vh_segment segs[2]; int ns = 0;
         segs[ns++] = vh_segment{ptr(n, pr.src), 0, cfg.warp_depth_coor ? 3 : src_c, src_c, 1, 0};
         if (cfg.warp_depth_coor) segs[ns++] = vh_segment{ptr(n, sgrid), 1, 128, 128, 1, 0};
-        Buf xin = assemble(n, segs, ns, rows_all, R, round_up(n->enc.in_channels, 8), pr.sigma);
+        Buf xin = assemble(n, segs, ns, rows_all, R, round_up(n->enc.in_channels, n->fp32 ? 4 : 8), pr.sigma);
         release(n, sgrid);
         Buf cvec = embedding(n, "encoder.", n->enc, n->embE, rows_all, pr.sigma, 1, cfg.no_time_enc ? 0.f : 1.f, pr.geometry, cfg.source_label_dim);
         Buf last = run_unet(n, "encoder.", n->enc, n->embE, rows_all, xin, cvec, nullptr, true, 0.f, nsrc, &feats);
@@ -612,14 +753,19 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
         segs[ns++] = vh_segment{ptr(n, pr.x), 0, cfg.img_channels, cfg.img_channels, rm, 1};
         if (cfg.warp_depth_coor) segs[ns++] = vh_segment{ptr(n, dgrid), 1, 128, 128, rm, 0};
         if (cfg.super_res) segs[ns++] = vh_segment{ptr(n, pr.cond), 0, cfg.img_channels, cfg.img_channels, 1, 0};
-        Buf xin = assemble(n, segs, ns, B, R, round_up(n->unet.in_channels, 8), pr.sigma);
+        Buf xin = assemble(n, segs, ns, B, R, round_up(n->unet.in_channels, n->fp32 ? 4 : 8), pr.sigma);
         release(n, dgrid);
         Buf cvec = embedding(n, "unet.", n->unet, n->embU, B, pr.sigma, rm, 1.f, pr.geometry, cfg.target_label_dim);
         const float n_zero = have_feats ? 0.f : (float)nsrc;
         Buf last = run_unet(n, "unet.", n->unet, n->embU, B, xin, cvec, have_feats ? use : nullptr, false, n_zero, nsrc, nullptr);
-        auto ls8 = split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false);
-        Buf F = conv(n, ls8.first, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
-        release(n, ls8.first); release(n, last); release(n, cvec);
+        Buf F;
+        if (n->fp32) F = conv_f32(n, last, n->W.at("unet.out_conv.weight"), B, R, R, ConvF{});
+        else {
+            auto ls8 = split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false);
+            F = conv(n, ls8.first, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
+            release(n, ls8.first);
+        }
+        release(n, last); release(n, cvec);
         vh_precond_out_args po{}; po.x = ptr(n, pr.x); po.row_mul = rm; po.f = ptr(n, F); po.fc = F.c; po.sigma = ptr(n, pr.sigma); po.sigma_data = (float)cfg.sigma_data;
         po.rows = B; po.c = cfg.img_channels; po.h = R; po.w = R; po.out = ptr(n, pr.D);
         call(n, vh_precond_out, po);
@@ -634,8 +780,13 @@ int check_config(const vh_net_config& c) {
     VH_REQUIRE(c.num_attn_resolutions >= 0 && c.num_attn_resolutions <= 8, "vh_net: bad attn_resolutions");
     VH_REQUIRE((c.img_resolution >> (c.num_levels - 1)) >= 1 && c.img_resolution % (1 << (c.num_levels - 1)) == 0, "vh_net: resolution not divisible by the level count");
     VH_REQUIRE(c.source_label_dim > 0 && c.target_label_dim >= 0 && c.logvar_channels > 0, "vh_net: bad label dims");
-    for (int i = 0; i < c.num_levels; ++i)
+    for (int i = 0; i < c.num_levels && !c.fp32; ++i)
         VH_REQUIRE((c.model_channels * c.channel_mult[i]) % 32 == 0, "vh_net: the bf16x3 path needs channel counts that are multiples of 32 (level %d has %d)", i, c.model_channels * c.channel_mult[i]);
+    VH_REQUIRE(c.resample_ntaps == 0 || (c.resample_ntaps >= 2 && c.resample_ntaps <= 8 && c.resample_ntaps % 2 == 0),
+               "vh_net: resample_filter must have 2, 4, 6 or 8 taps (the reference asserts an even length, training/models.py:52); got %d", c.resample_ntaps);
+    double tot = 0.0;
+    for (int i = 0; i < c.resample_ntaps; ++i) tot += (double)c.resample_filter[i];
+    VH_REQUIRE(c.resample_ntaps == 0 || tot != 0.0, "vh_net: resample_filter sums to zero");
     return VH_OK;
 }
 
@@ -669,7 +820,7 @@ void layout(vh_net* n) {
                 const std::string p = prefix + (g ? "dec." : "enc.") + b.name + ".";
                 if (b.conv) { add(p + "weight", 9, 0, 0, false); continue; }
                 add(p + "conv_res0.weight", 9, 0, 0, false);
-                if (b.dec && b.cin != b.cout) {
+                if (b.dec && b.cin != b.cout && !n->fp32) {
                     // conv_res1 + conv_skip of a decoder block as one GEMM (vh_conv_args.src1): rows of 9*Cout + Cin_pad K elements
                     Weight w; w.cout = b.cout; w.taps = 9; w.cin_pad = b.cout; w.k_pad = 9 * b.cout + round_up(b.cin, 32); w.off = cur; w.fused_c1 = round_up(b.cin, 32);
                     cur += (size_t)w.k_pad / 4 * w.cout * 4;
@@ -681,7 +832,7 @@ void layout(vh_net* n) {
                 }
                 if (b.heads) {
                     const int D = b.cout / b.heads;
-                    const bool fused = (b.res * b.res) % 32 == 0;      // VH_EPI_QKV needs 32 | pixels per image; else vh_qkv_split_x3 on an fp32 tensor
+                    const bool fused = !n->fp32 && (b.res * b.res) % 32 == 0;      // VH_EPI_QKV needs 32 | pixels per image; else vh_qkv_split_x3 on an fp32 tensor
                     add(p + "attn_qkv.weight", 1, fused ? 3 : 0, D, false);
                     add(p + "attn_proj.weight", 1, 0, 0, false);
                     if (b.xattn) add(p + "x_attn_kv.weight", 1, fused ? 2 : 0, D, false);
@@ -730,7 +881,7 @@ int prep_one(vh_net* n, const std::string& key, float* base) {
     vh_prep_weight_args a{};
     a.w = src; a.cout = cout; a.cin = cin; a.taps = w.taps; a.cin_pad = w.cin_pad; a.k_pad = w.k_pad;
     a.gain_ptr = w.has_gain ? P(n, key.substr(0, key.size() - std::string("out_conv.weight").size()) + "out_gain") : nullptr; a.gain_value = 1.f;
-    a.wt = w.wt; a.dst_col0 = 0; a.dst_cols = cout; a.split = p.ndim == 4 ? 2 : 0;
+    a.wt = w.wt; a.dst_col0 = 0; a.dst_cols = cout; a.split = (p.ndim == 4 && !n->fp32) ? 2 : 0;
     return vh_prep_weight(n->ctx, &a);
 }
 
@@ -741,7 +892,14 @@ extern "C" int vh_net_create(vh_ctx* ctx, const vh_net_config* cfg, vh_net** out
     const int rc = check_config(*cfg);
     if (rc != VH_OK) return rc;
     auto n = std::make_unique<vh_net>();
-    n->ctx = ctx; n->cfg = *cfg; n->has_enc = !cfg->uncond;
+    n->ctx = ctx; n->cfg = *cfg; n->has_enc = !cfg->uncond; n->fp32 = cfg->fp32 != 0;
+    if (cfg->resample_ntaps > 0) {                      // f / sum(f) (:53), the division in double like engine.Engine._resample
+        double tot = 0.0;
+        for (int i = 0; i < cfg->resample_ntaps; ++i) tot += (double)cfg->resample_filter[i];
+        n->ntaps = cfg->resample_ntaps;
+        for (int i = 0; i < n->ntaps; ++i) n->taps[i] = (float)((double)cfg->resample_filter[i] / tot);
+        n->std_filter = n->ntaps == 2 && cfg->resample_filter[0] == 1.f && cfg->resample_filter[1] == 1.f;
+    }
     if (n->has_enc) { n->enc = make_spec(*cfg, true); spec_params(n->enc, "encoder.", false, n->params); }
     n->unet = make_spec(*cfg, false); spec_params(n->unet, "unet.", true, n->params);
     auto add = [&](const char* name, std::initializer_list<int> shp) {
