@@ -245,6 +245,37 @@ def test_conv_patch_kernel_shapes(ctx, rows, h, w, cin, epi):
         assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5, tile
 
 
+@pytest.mark.parametrize("rows,h,w,cin,cout", [(2, 40, 17, 64, 3), (1, 32, 48, 128, 3), (1, 16, 16, 32, 16), (3, 256, 256, 64, 3)])
+def test_conv_patch_kernel_narrow_output(ctx, rows, h, w, cin, cout):
+    """conv_x3_patch's 16-column instantiation (Cout <= 16, plain store: UNet.out_conv, training/models.py:480 - 3 channels with out_gain folded
+    into the weights): two chunks with the look-ahead patch, four without, one; ragged tiles; forced (tile 8) and by the size rule (AUTO at
+    768 tiles), equal to the 256x64 tile's result up to summation order; rows of 12 bytes, so the neighbours of every store are checked too."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(rows + h + w + cin + cout)
+    x = torch.randn(rows, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g)
+    ref = R.mp_conv(x, wgt, gain=0.7)
+    M = rows * h * w
+    xd = _nhwc(x).cuda()
+    xs8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2, gain=0.7)
+    outs = {}
+    for tile in (8, 0, 5):
+        buf = torch.full((M * cout + 8,), float("nan"), device="cuda")       # (4 guard floats on either side)
+        out = buf[4:4 + M * cout]
+        ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0,
+                                      taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536,
+                                      scratch=None, scratch_floats=0, cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0,
+                                      prec=1, kernel=1, epi=0, cvec=None, cvec_ld=0, res=None, res_up=0, ta=0, tb=0, clip=0, korder=0, tile=tile))
+        torch.cuda.synchronize()
+        assert torch.isnan(buf[:4]).all() and torch.isnan(buf[-4:]).all(), tile
+        assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5, tile
+        outs[tile] = out.clone()
+    assert rel_l2(outs[8].cpu(), outs[5].cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("cout,c1,epi", [(64, 0, 2), (64, 64, 0), (128, 0, 0), (128, 0, 2), (256, 0, 1)])
 def test_conv_s8_sinks_equal_split_of_the_result(ctx, cout, c1, epi):
     """vh_s8_sink: a convolution on the patch-resident kernel writes the scaled / mp_silu'd S8 forms of its result straight into a channel range

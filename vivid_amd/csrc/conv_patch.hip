@@ -153,12 +153,14 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
 // with four or six (the extra LDS traffic and the address work sit in a K loop that is MFMA-paced while both workgroups of the CU are in
 // theirs): the launcher takes it for cin_pad <= 64 only.
 // NJ: 16-channel N tiles per wave - 4 (Cout <= 64), 8 (128 channels per workgroup: 64 accumulator registers, 16 KB weight stages, 73 KB of LDS) or
-// 6 (96: Cout = 192 as two blocks, where 128-channel blocks would leave the second half empty).
+// 6 (96: Cout = 192 as two blocks, where 128-channel blocks would leave the second half empty) or 1 (Cout <= 16, plain store: UNet.out_conv's 3
+// channels - on a 64-wide tile 61 of 64 MFMA columns are idle and the layer is MFMA-bound on them; 16 columns leave it to the patch's LDS reads).
 // TAIL: 0 no second source; 1 the 1-tap tail through two 32 KB LDS-DMA stages (NJ = 4 only: 80 KB with the weights); 2 through registers and a
 // wave-private 4 KB LDS area (any NJ: each wave's 32 pixels are read by that wave alone, so their staging needs no barrier and no second stage).
 template <int NJ, int TAIL, bool PF>
 __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
-    static_assert(NJ == 4 || NJ == 6 || NJ == 8, "64, 96 or 128 output channels per workgroup");
+    static_assert(NJ == 1 || NJ == 4 || NJ == 6 || NJ == 8, "16 (narrow outputs: the 3-channel out_conv), 64, 96 or 128 output channels per workgroup");
+    static_assert(!(NJ == 1 && TAIL != 0), "the narrow form has no tail segment");
     static_assert(!(TAIL == 1 && NJ > 4), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
     static_assert(!(PF && NJ > 4), "the landing pad of the next chunk's pieces and 32 KB of weight stages do not fit half a CU's LDS");
     constexpr int BN = NJ * 16, RB = (BN + 63) / 64;         // output channels per workgroup; weight DMA pieces per wave and K-tile (stage = RB * 64 rows)
@@ -491,6 +493,26 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     if (yb >= a.h) return;
     // (the lane id re-derived from the hardware counter: carried over from the prologue it costs the K loop a register it does not have)
     const int le = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if constexpr (NJ == 1) {
+        // narrow output (Cout <= 16, VH_EPI_STORE): straight from the accumulators - C/D map of the 16x16 tile: column = lane & 15, pixels
+        // 4 * (lane >> 4) + r of tile row 2w + i; 12 B per pixel at Cout = 3, no transpose worth making
+        const int col = le & 15, xq = x0 + 4 * (le >> 4);
+        if (col < a.cout) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = yb + i;
+                if (yy >= a.h) continue;
+                float* orow = a.out + ((size_t)img * a.HW + (size_t)yy * a.w) * a.cout + col;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][0][r];
+                    if (a.clip > 0.f) v = fminf(fmaxf(v, -a.clip), a.clip);
+                    if (xq + r < a.w) orow[(size_t)(xq + r) * a.cout] = v;
+                }
+            }
+        }
+        return;
+    }
     auto run = [&](auto epic) __attribute__((always_inline)) {
         constexpr int EPI = decltype(epic)::value;
         const int cb = nb * BN;                                // first output channel of this workgroup
@@ -537,6 +559,13 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
     k.div_ptiles = vhconv::fastdiv_make((unsigned)(k.ptx * k.pty));
     // 128 (or 96) output channels per workgroup beyond 64; with a tail segment the wave-private form (TAIL = 2) serves every block width,
     // knob "conv_patch_tail": 2 (default) always, 1 the LDS-DMA staged tail where it exists (64-channel blocks)
+    if (k.cout <= 16) {                                      // narrow outputs (validated by vh_conv_patch_choice: plain store, no tail, no S8 forms)
+        k.NT = 1;
+        const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty);
+        if (k.cin_pad <= 64) hipLaunchKernelGGL((conv_x3_patch<1, 0, true>), dim3(grid), dim3(512), 0, s, k);
+        else hipLaunchKernelGGL((conv_x3_patch<1, 0, false>), dim3(grid), dim3(512), 0, s, k);
+        return;
+    }
     const int tmode = k.c1 > 0 ? (vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1 ? 1 : 2) : 0;
     const bool wide = k.cout > 64 && tmode != 1;
     const bool n96 = wide && k.cout % 96 == 0 && k.cout % 128 != 0;

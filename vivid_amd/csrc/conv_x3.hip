@@ -633,7 +633,8 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s);      // conv_patch
 // Patch-resident kernel (conv_patch.hip): does it run these (validated) arguments?  1 yes, 0 no, -1 = VH_TILE_PATCH16 forced on ineligible ones.
 int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out) {
     // (the kernel addresses its inputs through 32-bit offsets in 16-byte units: M * c / 4 < 2^32)
-    const bool patch_ok = a.taps == 9 && !a.up && a.cout % 32 == 0 && a.epi != VH_EPI_QKV &&
+    const bool narrow = a.cout <= 16 && a.epi == VH_EPI_STORE && !a.src1 && !a.out_s8 && !a.sink[0].ptr && !a.sink[1].ptr && a.out;   // UNet.out_conv
+    const bool patch_ok = a.taps == 9 && !a.up && (a.cout % 32 == 0 || narrow) && a.epi != VH_EPI_QKV &&
                           a.prec == VH_PREC_BF16X3 && a.kernel == VH_CONV_GLDS256 &&
                           (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0;
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
@@ -641,7 +642,7 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     const bool tailp = a.src1 != nullptr;
     const bool wide_ok = !tailp || vh_knob(VH_KNOB_CONV_PATCH_TAIL) != 1;                                           // (the staged tail exists for 64-channel blocks only)
     const bool n96 = a.cout > 64 && wide_ok && a.cout % 96 == 0 && a.cout % 128 != 0;                               // 96-channel blocks (Cout = 192)
-    const long long pwgs = ptiles * (n96 ? a.cout / 96 : (a.cout > 64 && wide_ok) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
+    const long long pwgs = narrow ? ptiles : ptiles * (n96 ? a.cout / 96 : (a.cout > 64 && wide_ok) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
     if (pwgs_out) *pwgs_out = pwgs;
     const int pknob = vh_knob(VH_KNOB_CONV_PATCH);
     // Size rule, from same-device A/B against the tile the rules of vh_conv_x3_glds_dispatch pick (profiles/r04_ab_conv_patch_vs_glds.txt): the patch
@@ -650,7 +651,8 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     // 32 tiles); Cout = 192 runs as two 96-channel blocks (+9..20 % over the 256x192 tile).  With a tail segment (wave-private staging, any block
     // width): +15..24 % at Cout = 64, +11..12 % at 128, +9 % at 192, +7 % at 384, ties (1.00-1.02x) at 256 and 512, which stay on conv_x3_glds.
     const int mres = a.h < a.w ? a.h : a.w;
-    const bool patch_rule = pwgs >= 256 && mres >= 32 && (a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) &&
+    // Narrow outputs (Cout <= 16: the 3-channel out_conv) take a 16-column instantiation: on the 256x64 tile the layer is bound by MFMAs on 61 idle columns
+    const bool patch_rule = pwgs >= 256 && mres >= 32 && (narrow || a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) &&
                             (!tailp || a.cout <= 192 || (a.cout == 384 && wide_ok)) && (mres >= 64 || a.cout <= 256);
     return (patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))))) ? 1 : 0;
 }
@@ -661,7 +663,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     {
         long long pwgs = 0;
         const int pc = vh_conv_patch_choice(a, M, &pwgs);
-        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up`, cout %% 32 == 0 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
+        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up`, cout %% 32 == 0 or a plain fp32 store of cout <= 16 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
         if ((a.sink[0].ptr || a.sink[1].ptr) && pc != 1)
             return vh_fail(VH_EINVAL, "vh_conv: S8 sinks given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
         if (pc == 1) {
