@@ -63,6 +63,8 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  *   the convolutions that produce them (vh_s8_sink) - 2 both halves, 1 the x half only, 0 (default) never (a vh_split pass over the fp32 tensors);
  * "conv_patch96": 1 (default) Cout = 192 layers run the patch-resident kernel as two 96-channel blocks, 0: the 256x192 tile (A/B);
  * "conv_patch_tail": tail segment of the patch-resident kernel - 2 (default) staged per wave through registers, 1 through two LDS-DMA stages (A/B);
+ * "conv_tail_f32": vh_conv_args.tail_f32 launches (and the whole-network walks, which ask vh_conv_takes_patch per decoder block) - 1 (default) wherever the
+ *   patch-resident kernel takes a tail segment plus Cout = 256 from 64x64 up, 0 never (the walks fall back to vh_split's raw S8 form), 2 also Cout = 512 (A/B);
  * "conv_patch_delay": start delay, in units of 2048 shader cycles, of every CU's second workgroup in the first round of a patch-kernel launch.
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);
@@ -208,6 +210,12 @@ typedef struct {
     vh_s8_sink sink[2];                    /* optional extra S8 outputs (see vh_s8_sink); only a launch that takes the patch-resident kernel writes them
                                               (vh_conv_takes_patch() == 1 or tile == VH_TILE_PATCH16), any other is refused.  With a sink, `out` and
                                               `out_s8` may both be NULL. */
+    int tail_f32;                          /* 1: the 1-tap tail segment is read from fp32 NHWC tensors instead of an S8 one - `src1` (c1 channels, times scale1)
+                                              and optionally `src2` (c2 channels, times scale2) as a channel concat, i.e. mp_cat(x, skip) itself
+                                              (training/models.py:78-84): the scaled values are split into bf16 hi / lo while the tail is staged, the
+                                              bits vh_split would have written as the raw S8 form.  c1, c2 multiples of 32, k_pad = 9*cin_pad + c1 + c2.
+                                              Patch-resident kernel only (ask vh_conv_takes_patch with these fields set; refused otherwise). */
+    const float* src2; int c2; float scale2;
 } vh_conv_args;
 enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
 enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5, VH_TILE_256x192 = 7,

@@ -317,3 +317,39 @@ def test_concat_fusion_modes_change_nothing(name):
         os.environ.pop("VIVID_FUSE_CONCAT", None)
         _lib.set_knob("fuse_concat", 0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_fp32_tail_segment_changes_nothing():
+    """vh_conv_args.tail_f32 (knob "conv_tail_f32"): the fused conv_res1 + conv_skip launches of the decoder read mp_cat(x, skip) from the fp32
+    tensors and split it into bf16 hi / lo while staging, so vh_split writes one S8 form of the concat instead of two.  The staged bits are the
+    bits vh_split wrote: the reference's SR stage at full size (the smallest preset whose tails take the patch kernel) must give EQUAL outputs with
+    the knob on (default), off, and extended to the 256 / 512-channel blocks - in both walks."""
+    import vivid_amd
+    from vivid_amd import _lib
+    from vivid_amd.cnet import CNet
+    cfg, seed = vivid_amd.vivid_sr(256, noisy_sr=0.0), 3
+    g = torch.Generator().manual_seed(9)
+    src, geo = (torch.rand(2, 3, 256, 256, generator=g) * 2 - 1).cuda(), torch.randn(2, 20, generator=g).cuda()
+    cond = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).cuda()
+    x, sig = (torch.randn(2, 3, 256, 256, generator=g) * 2).cuda(), torch.full((2,), 1.3).cuda()
+    sd = vivid_amd.synth_state_dict(cfg, seed=seed)
+    outs, tails = [], []
+    try:
+        for mode in (1, 0, 2):
+            _lib.set_knob("conv_tail_f32", mode)
+            net = vivid_amd.NVPrecond.from_config(cfg, precision="bf16x3")
+            net.load_state_dict(sd, strict=True)
+            net.noisy_sr = 0.0
+            net = net.cuda()
+            a = net(src, x, sig, geo, cond)
+            cn = CNet(cfg)
+            cn.load_state_dict(sd)
+            b = cn(src, x, sig, geo, cond)
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), mode
+            outs.append(a)
+            tails.append(sum("tail=fp32" in d for d in list(net._engine.programs.values())[0].oplog))
+    finally:
+        _lib.set_knob("conv_tail_f32", 1)
+    assert tails[1] == 0 and tails[0] > 0 and tails[2] >= tails[0], tails
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

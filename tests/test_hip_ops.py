@@ -4,6 +4,7 @@
 Tolerances: fp32 kernels 2e-5 rel-L2 (summation order, hardware exp2/rcp); bf16x3 kernels 1e-4
 (hi/lo split drops ~2^-16 of each product) — both far inside north_star's 1e-3."""
 import ctypes
+import ctypes as C
 import math
 
 import pytest
@@ -385,6 +386,46 @@ def test_conv_glds_tail_segment(ctx, tile, cout, c1, scratch, korder):
     torch.cuda.synchronize()
     assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5
     assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5
+
+
+@pytest.mark.parametrize("cout,na,nb,cin,h,w", [(64, 64, 64, 64, 40, 24), (64, 128, 0, 64, 32, 32), (128, 256, 128, 128, 48, 32), (192, 192, 192, 192, 32, 32),
+                                                (256, 256, 256, 256, 32, 48), (384, 128, 64, 64, 24, 40)])
+def test_conv_fp32_tail_equals_s8_tail(ctx, cout, na, nb, cin, h, w):
+    """vh_conv_args.tail_f32: the 1-tap tail segment of a fused conv_res1 + conv_skip launch read from the fp32 tensors x and skip themselves
+    (mp_cat's weights and the bf16 hi / lo split applied while the tail is staged) instead of the raw S8 concat vh_split would write - the result
+    must be the SAME BITS, for every block width of the patch kernel (64 with and without the look-ahead patch, 96, 128), one and two sources,
+    ragged tiles; ask-first protocol (vh_conv_takes_patch) and the refusal when the launch would not take the patch kernel."""
+    from vivid_amd import _lib as L
+    rows = 2
+    g = torch.Generator().manual_seed(cout + na + nb + cin)
+    M = rows * h * w
+    y = torch.randn(M, cin, generator=g).cuda()
+    xa = torch.randn(M, na, generator=g).cuda()
+    xb = torch.randn(M, nb, generator=g).cuda() if nb else None
+    sa, sb = 0.83, 1.21
+    ys8 = torch.empty(M * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=y.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin, out=ys8.data_ptr(), out_raw=None))
+    craw = torch.empty(M * (na + nb), device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xa.data_ptr(), src1=xb.data_ptr() if nb else None, c0=na, c1=nb, scale0=sa, scale1=sb, pro=0, npix=M, c_pad=na + nb,
+                                     out=craw.data_ptr(), out_raw=None))
+    k_pad = 9 * cin + na + nb
+    wt = torch.randn(k_pad // 4 * cout * 4, generator=g).cuda() * 0.05          # (any weights: both launches read the same prepared buffer)
+    wt = wt.view(torch.int32).bitwise_and(-65536).view(torch.float32)           # (valid bf16 pairs in both halves of every unit: no NaN patterns)
+    common = dict(src0=ys8.data_ptr(), c0=cin, scale0=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=_zeros(),
+                  zeros_bytes=65536, scratch=None, scratch_floats=0, cout=cout, out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=0, tile=8)
+    o1 = torch.empty(M, cout, device="cuda")
+    ctx.call("vh_conv", L.ConvArgs(src1=craw.data_ptr(), c1=na + nb, scale1=1.0, out=o1.data_ptr(), **common))
+    o2 = torch.full((M, cout), float("nan"), device="cuda")
+    a = L.ConvArgs(src1=xa.data_ptr(), c1=na, scale1=sa, src2=xb.data_ptr() if nb else None, c2=nb, scale2=sb if nb else 0.0, tail_f32=1, out=o2.data_ptr(), **common)
+    assert L.lib().vh_conv_takes_patch(C.byref(a)) == 1
+    ctx.call("vh_conv", a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1).all() and float(o1.abs().max()) > 0
+    assert torch.equal(o1, o2)
+    a.tile = 1                                                              # a forced conv_x3_glds tile has no fp32 tail
+    assert L.lib().vh_conv_takes_patch(C.byref(a)) == 0
+    with pytest.raises(L.VividHipError, match="tail_f32"):
+        ctx.call("vh_conv", a)
 
 
 def test_conv_tail_segment_is_validated(ctx):

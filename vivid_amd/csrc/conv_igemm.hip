@@ -254,16 +254,20 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     if (a.prec == VH_PREC_BF16X3) {
         VH_REQUIRE(a.pro == VH_PRO_NONE && a.scale0 == 1.0f, "vh_conv: bf16x3 takes pre-split (S8) sources; scale/silu/concat belong to their producer");
         VH_REQUIRE(a.c0 % 32 == 0 && a.cin_pad == a.c0, "vh_conv: bf16x3 needs c0 == cin_pad, a multiple of 32 (got %d, %d)", a.c0, a.cin_pad);
-        VH_REQUIRE(!tail || (a.kernel == VH_CONV_GLDS256 && a.taps == 9 && !a.up && a.c1 > 0 && a.c1 % 32 == 0 && a.scale1 == 1.0f && a.epi != VH_EPI_QKV),
+        VH_REQUIRE(!tail || (a.kernel == VH_CONV_GLDS256 && a.taps == 9 && !a.up && a.c1 > 0 && a.c1 % 32 == 0 && (a.scale1 == 1.0f || a.tail_f32) && a.epi != VH_EPI_QKV),
                    "vh_conv: a bf16x3 second source is the 1-tap tail of a 3x3 VH_CONV_GLDS256 convolution without `up` (c1 %% 32 == 0, scale1 == 1)");
     }
+    VH_REQUIRE(!a.tail_f32 || (tail && (a.src2 ? (a.c2 > 0 && a.c2 % 32 == 0 && vh_aligned16(a.src2)) : a.c2 == 0)),
+               "vh_conv: tail_f32 needs a bf16x3 tail segment: src1 (c1 %% 32 == 0) and optionally src2 (c2 %% 32 == 0), fp32 NHWC, 16-byte aligned");
+    VH_REQUIRE(a.tail_f32 || (!a.src2 && a.c2 == 0), "vh_conv: src2 / c2 belong to tail_f32");
+    const int tail_c = tail ? a.c1 + (a.tail_f32 ? a.c2 : 0) : 0;
     VH_REQUIRE(!a.out_s8 || (a.cout % 32 == 0 && a.out_s8_c == a.cout), "vh_conv: S8 output needs cout %% 32 == 0 and out_s8_c == cout");
     VH_REQUIRE(a.rows > 0 && a.h > 0 && a.w > 0 && a.cout > 0, "vh_conv: bad geometry");
     VH_REQUIRE(a.c0 > 0 && a.c0 % 4 == 0, "vh_conv: c0 must be a positive multiple of 4 (got %d)", a.c0);
     VH_REQUIRE(a.src1 ? (a.c1 > 0 && a.c1 % 4 == 0) : a.c1 == 0, "vh_conv: bad c1 %d", a.c1);
     VH_REQUIRE(a.cin_pad % BK == 0 && a.cin_pad >= a.c0 + (tail ? 0 : a.c1), "vh_conv: cin_pad %d must be a multiple of %d and >= c0+c1 = %d", a.cin_pad, BK, a.c0 + a.c1);
-    VH_REQUIRE(a.k_pad == a.taps * a.cin_pad + (tail ? a.c1 : 0), "vh_conv: k_pad %d != taps*cin_pad%s %d", a.k_pad, tail ? " + c1" : "", a.taps * a.cin_pad + (tail ? a.c1 : 0));
-    VH_REQUIRE(a.zeros && vh_aligned16(a.zeros) && a.zeros_bytes >= (size_t)std::max(a.cin_pad, tail ? a.c1 : 0) * 4 + 64, "vh_conv: zero page missing or smaller than max(cin_pad, c1)*4+64 bytes");
+    VH_REQUIRE(a.k_pad == a.taps * a.cin_pad + tail_c, "vh_conv: k_pad %d != taps*cin_pad%s %d", a.k_pad, tail ? " + c1 (+ c2)" : "", a.taps * a.cin_pad + tail_c);
+    VH_REQUIRE(a.zeros && vh_aligned16(a.zeros) && a.zeros_bytes >= (size_t)std::max(a.cin_pad, tail ? std::max(a.c1, a.c2) : 0) * 4 + 64, "vh_conv: zero page missing or smaller than max(cin_pad, c1)*4+64 bytes");
     VH_REQUIRE(vh_aligned16(a.src0) && vh_aligned16(a.src1) && vh_aligned16(a.wt), "vh_conv: source/weight pointers must be 16-byte aligned");
     // the epilogues read the residual / cvec rows and write the fp32 / S8 outputs as 16-byte vectors whenever cout % 4 == 0
     VH_REQUIRE(a.cout % 4 != 0 || (vh_aligned16(a.out) && vh_aligned16(a.out_s8) && vh_aligned16(a.res) && (a.cvec_ld % 4 != 0 || vh_aligned16(a.cvec))),
@@ -304,6 +308,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.div_hw = fastdiv_make((unsigned)(a.h * a.w)); k.div_w = fastdiv_make((unsigned)a.w); k.div_c0u = fastdiv_make((unsigned)(a.c0 / 4));
     k.ksplit = 1; k.scratch = nullptr; k.korder = 0; k.stagger = 0; k.dbg = nullptr;
     k.ptx = k.pty = 0; k.div_ptx = k.div_ptiles = fastdiv_make(1);
+    k.src2 = a.src2; k.c2 = a.c2; k.scale2 = a.scale2; k.tail_f32 = a.tail_f32 ? 1 : 0;
     for (int i = 0; i < 2; ++i) {
         k.sk_ptr[i] = static_cast<unsigned short*>(a.sink[i].ptr); k.sk_ct[i] = a.sink[i].c_total; k.sk_off[i] = a.sink[i].c_off;
         k.sk_scale[i] = a.sink[i].scale; k.sk_silu[i] = a.sink[i].silu;
@@ -320,9 +325,9 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     const unsigned grid = (unsigned)(MT * NT);
     // algorithmic work: 2*M*cout*cin*taps FLOPs; bytes = input + weights + output (+ residual), each once
     const double cin = tail ? (double)a.c0 : (double)a.c0 + a.c1;
-    const double flops = 2.0 * (double)M * a.cout * (cin * a.taps + (tail ? a.c1 : 0));
+    const double flops = 2.0 * (double)M * a.cout * (cin * a.taps + tail_c);
     const double in_px = a.up ? (double)M / 4 : (double)M;
-    double bytes = 4.0 * (in_px * cin + cin * a.taps * a.cout + (double)M * a.cout + (tail ? (double)M * a.c1 + (double)a.c1 * a.cout : 0.0));
+    double bytes = 4.0 * (in_px * cin + cin * a.taps * a.cout + (double)M * a.cout + (tail ? (double)M * tail_c + (double)tail_c * a.cout : 0.0));
     if (a.epi == VH_EPI_MPSUM) bytes += 4.0 * (a.res_up ? (double)M / 4 : (double)M) * a.cout;
     VH_REQUIRE(a.kernel == VH_CONV_TILE128 || (a.kernel == VH_CONV_GLDS256 && a.prec == VH_PREC_BF16X3),
                "vh_conv: kernel %d unknown or not available for this precision", a.kernel);

@@ -147,6 +147,22 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
     }
 }
 
+// a * b rounded to fp32, never contracted into a following add / subtract (HIP's __fmul_rn is a plain `*` that -ffp-contract=fast may fuse:
+// the fp32 tail must produce split_k's bits, whose product is rounded before the hi / lo split subtracts from it)
+__device__ __forceinline__ float mul_rounded(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+
+// (a, b) -> packed bf16 hi pair and lo pair of the hi + lo split (one v_cvt_pk_bf16_f32 per pair; the roundings of split_k / bf16_rn_bits)
+__device__ __forceinline__ void bf16_split_pair_p(float a, float b, unsigned& H, unsigned& L) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t h; h[0] = (__bf16)a; h[1] = (__bf16)b;
+    H = __builtin_bit_cast(unsigned, h);
+    bf16x2_t q; q[0] = (__bf16)(a - __uint_as_float(H << 16)); q[1] = (__bf16)(b - __uint_as_float(H & 0xFFFF0000u));
+    L = __builtin_bit_cast(unsigned, q);
+}
+
 // PF: the next chunk's patch is requested during this chunk's taps (two pieces by LDS-DMA into a landing pad, three into registers - the
 // loop cannot hold all five) and moved into place at the boundary, instead of being fetched there.  Same-device A/B: the boundary itself
 // shrinks from 2.0 to 0.45 us (s_memtime stamps), worth +3 % with two chunks (64 input channels: one boundary, short K loop) and -2.5 %
@@ -156,11 +172,14 @@ __device__ __forceinline__ void patch_block_out(const ConvK& a, const f32x4 t00,
 // 6 (96: Cout = 192 as two blocks, where 128-channel blocks would leave the second half empty) or 1 (Cout <= 16, plain store: UNet.out_conv's 3
 // channels - on a 64-wide tile 61 of 64 MFMA columns are idle and the layer is MFMA-bound on them; 16 columns leave it to the patch's LDS reads).
 // TAIL: 0 no second source; 1 the 1-tap tail through two 32 KB LDS-DMA stages (NJ = 4 only: 80 KB with the weights); 2 through registers and a
-// wave-private 4 KB LDS area (any NJ: each wave's 32 pixels are read by that wave alone, so their staging needs no barrier and no second stage).
+// wave-private 4 KB LDS area (any NJ: each wave's 32 pixels are read by that wave alone, so their staging needs no barrier and no second stage);
+// 3 = 2 with fp32 sources (vh_conv_args.tail_f32): the registers the pieces pass through anyway are where mp_cat's scale and the bf16 hi / lo split
+// are applied, so no raw S8 form of the concat has to exist in memory.
 template <int NJ, int TAIL, bool PF>
 __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     static_assert(NJ == 1 || NJ == 4 || NJ == 6 || NJ == 8, "16 (narrow outputs: the 3-channel out_conv), 64, 96 or 128 output channels per workgroup");
     static_assert(!(NJ == 1 && TAIL != 0), "the narrow form has no tail segment");
+    static_assert(TAIL >= 0 && TAIL <= 3, "tail modes 0-3");
     static_assert(!(TAIL == 1 && NJ > 4), "the tail's two 32 KB stages and 32 KB of weight stages do not fit half a CU's LDS");
     static_assert(!(PF && NJ > 4), "the landing pad of the next chunk's pieces and 32 KB of weight stages do not fit half a CU's LDS");
     constexpr int BN = NJ * 16, RB = (BN + 63) / 64;         // output channels per workgroup; weight DMA pieces per wave and K-tile (stage = RB * 64 rows)
@@ -292,7 +311,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
     // ---- main loop: chunks of 32 channels; per chunk the patch is staged once and the nine taps run against it -------------------------
     const int nch = a.cin_pad >> 5;
-    const int ntail = TAIL != 0 ? (a.c1 >> 5) : 0;
+    const int ntail = TAIL == 3 ? ((a.c1 + a.c2) >> 5) : TAIL != 0 ? (a.c1 >> 5) : 0;
 #ifdef VH_CLOCK
     PCK(ck_p1);
 #endif
@@ -419,6 +438,71 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
                     for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
                 }
                 if (c + 1 < ntail) wait_dma_but<4>();                        // the next weight tile has landed; the four fragment loads behind it stay in flight
+                else wait_dma_p();
+                __syncthreads();
+                st ^= 1;
+            }
+        }
+    }
+    if constexpr (TAIL == 3) {
+        // TAIL == 2 with fp32 sources: K-tiles 0 .. c1/32-1 of the tail come from src1 (fp32 NHWC, c1 channels, times scale1), the rest from src2
+        // (c2 channels, times scale2) - mp_cat(x, skip) itself (training/models.py:78-84).  Lane (pixel q = (lane>>3) + 8j, quad cq = lane & 7) loads
+        // channels 4cq..4cq+3 of the K-tile (8 lanes = the pixel's 128 bytes), scales, splits (the operations and roundings of split_k's raw form)
+        // and writes 8 bytes of hi unit cq>>1 and 8 bytes of lo unit 4 + (cq>>1) of its wave's private [32 pixels][8 units] area.
+        if (ntail > 0) {
+            const int lt = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), l15t = lt & 15, kgt = lt >> 4;
+            const int brow16t = l15t * 8, u16ht = kgt ^ (l15t >> 1);
+            const int n1 = a.c1 >> 5;                                       // K-tiles of the first source
+            f32x4 nx[4];
+            auto fetchA = [&](int c) __attribute__((always_inline)) {
+                int lq = lt;
+                asm volatile("" : "+v"(lq));
+                const bool first = c < n1;
+                const float4* s4 = reinterpret_cast<const float4*>(first ? a.src1 : a.src2);
+                const unsigned cs4 = (unsigned)((first ? a.c1 : a.c2) >> 2), cu = (unsigned)(first ? c : c - n1) * 8u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = (lq >> 3) + 8 * j, cq = lq & 7;
+                    const int yy = y0 + 2 * w + (q >> 4), xx = x0 + (q & 15);
+                    const bool inside = yy < a.h && xx < a.w;
+                    nx[j] = *reinterpret_cast<const f32x4*>(inside ? s4 + (size_t)((img_off + (unsigned)(yy * a.w + xx)) * cs4 + (unsigned)cq + cu) : zp);
+                }
+            };
+            fetchA(0);
+            uint2* const mine2 = reinterpret_cast<uint2*>(sA + w * 256);    // this wave's [32 pixels][8 units of 16 B], as 8-byte halves
+            const float4* const mine = sA + w * 256;
+            for (int c = 0; c < ntail; ++c) {
+                const float sc = c < n1 ? a.scale1 : a.scale2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int q = (lt >> 3) + 8 * j, cq = lt & 7;
+                    unsigned H0, L0, H1, L1;
+                    bf16_split_pair_p(mul_rounded(nx[j][0], sc), mul_rounded(nx[j][1], sc), H0, L0);
+                    bf16_split_pair_p(mul_rounded(nx[j][2], sc), mul_rounded(nx[j][3], sc), H1, L1);
+                    const int slot = q * 8 + ((cq >> 1) ^ (q & 7));           // hi unit cq>>1 of pixel q (swizzled like the patch); its lo unit is slot ^ 4
+                    mine2[slot * 2 + (cq & 1)] = make_uint2(H0, H1);
+                    mine2[(slot ^ 4) * 2 + (cq & 1)] = make_uint2(L0, L1);
+                }
+                if (c + 1 < ntail) {
+                    issueB(st ^ 1, (9 * a.cin_pad + (c + 1) * 32) >> 2);
+                    fetchA(c + 1);
+                }
+                bf16x8 ah[2], al[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int q = i * 16 + l15t;
+                    const int ih = q * 8 + (kgt ^ (q & 7));
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&mine[ih]);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&mine[ih ^ 4]);
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&sB[st][brow16t + j * 128 + u16ht]);
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&sB[st][(brow16t + j * 128 + u16ht) ^ 4]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) mfma3(acc[i][j], ah[i], al[i], bh, bl);
+                }
+                if (c + 1 < ntail) wait_dma_but<4>();
                 else wait_dma_p();
                 __syncthreads();
                 st ^= 1;
@@ -566,7 +650,7 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
         else hipLaunchKernelGGL((conv_x3_patch<1, 0, false>), dim3(grid), dim3(512), 0, s, k);
         return;
     }
-    const int tmode = k.c1 > 0 ? (vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1 ? 1 : 2) : 0;
+    const int tmode = k.c1 > 0 ? (k.tail_f32 ? 3 : vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1 ? 1 : 2) : 0;
     const bool wide = k.cout > 64 && tmode != 1;
     const bool n96 = wide && k.cout % 96 == 0 && k.cout % 128 != 0;
     const int bn = n96 ? 96 : wide ? 128 : 64;
@@ -578,8 +662,10 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
         if (n96) VH_PATCH_LAUNCH(6, 0, false); else if (wide) VH_PATCH_LAUNCH(8, 0, false); else if (pf) VH_PATCH_LAUNCH(4, 0, true); else VH_PATCH_LAUNCH(4, 0, false);
     } else if (tmode == 1) {
         if (pf) VH_PATCH_LAUNCH(4, 1, true); else VH_PATCH_LAUNCH(4, 1, false);
-    } else {
+    } else if (tmode == 2) {
         if (n96) VH_PATCH_LAUNCH(6, 2, false); else if (wide) VH_PATCH_LAUNCH(8, 2, false); else if (pf) VH_PATCH_LAUNCH(4, 2, true); else VH_PATCH_LAUNCH(4, 2, false);
+    } else {
+        if (n96) VH_PATCH_LAUNCH(6, 3, false); else if (wide) VH_PATCH_LAUNCH(8, 3, false); else if (pf) VH_PATCH_LAUNCH(4, 3, true); else VH_PATCH_LAUNCH(4, 3, false);
     }
 #undef VH_PATCH_LAUNCH
 }

@@ -636,10 +636,12 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     const bool narrow = a.cout <= 16 && a.epi == VH_EPI_STORE && !a.src1 && !a.out_s8 && !a.sink[0].ptr && !a.sink[1].ptr && a.out;   // UNet.out_conv
     const bool patch_ok = a.taps == 9 && !a.up && (a.cout % 32 == 0 || narrow) && a.epi != VH_EPI_QKV &&
                           a.prec == VH_PREC_BF16X3 && a.kernel == VH_CONV_GLDS256 &&
-                          (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0;
+                          (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0 && (double)M * a.c2 / 4.0 < 4294967296.0;
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
     const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
     const bool tailp = a.src1 != nullptr;
+    const int tf = vh_knob(VH_KNOB_CONV_TAIL_F32);
+    if (a.tail_f32 && (tf == 0 || vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1)) return a.tile == VH_TILE_PATCH16 ? -1 : 0;      // (fp32 tails exist in the wave-private form only)
     const bool wide_ok = !tailp || vh_knob(VH_KNOB_CONV_PATCH_TAIL) != 1;                                           // (the staged tail exists for 64-channel blocks only)
     const bool n96 = a.cout > 64 && wide_ok && a.cout % 96 == 0 && a.cout % 128 != 0;                               // 96-channel blocks (Cout = 192)
     const long long pwgs = narrow ? ptiles : ptiles * (n96 ? a.cout / 96 : (a.cout > 64 && wide_ok) ? (a.cout + 127) / 128 : (a.cout + 63) / 64);      // workgroups the patch kernel would launch
@@ -650,10 +652,12 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     // 32^2 x 512 and loses where its 16x16-pixel tiles do not fit the image (16^2: 0.6-0.87x, 8^2: 0.38x), on small grids (no split-K: 0.35-0.67x at
     // 32 tiles); Cout = 192 runs as two 96-channel blocks (+9..20 % over the 256x192 tile).  With a tail segment (wave-private staging, any block
     // width): +15..24 % at Cout = 64, +11..12 % at 128, +9 % at 192, +7 % at 384, ties (1.00-1.02x) at 256 and 512, which stay on conv_x3_glds.
+    // An fp32 tail (tail_f32) costs the launch 1.4-4 % and saves vh_split a third of its bytes (10x that): taken wherever the S8 tail is, and at
+    // Cout = 256 from 64^2 up, where the convolution then ties with conv_x3_glds' S8 tail (1.00x) and the split saving is the gain.
     const int mres = a.h < a.w ? a.h : a.w;
     // Narrow outputs (Cout <= 16: the 3-channel out_conv) take a 16-column instantiation: on the 256x64 tile the layer is bound by MFMAs on 61 idle columns
     const bool patch_rule = pwgs >= 256 && mres >= 32 && (narrow || a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) &&
-                            (!tailp || a.cout <= 192 || (a.cout == 384 && wide_ok)) && (mres >= 64 || a.cout <= 256);
+                            (!tailp || a.cout <= 192 || (a.cout == 384 && wide_ok) || (a.tail_f32 && (tf == 2 || (a.cout == 256 && mres >= 64)))) && (mres >= 64 || a.cout <= 256);
     return (patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))))) ? 1 : 0;
 }
 
@@ -666,6 +670,8 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up`, cout %% 32 == 0 or a plain fp32 store of cout <= 16 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
         if ((a.sink[0].ptr || a.sink[1].ptr) && pc != 1)
             return vh_fail(VH_EINVAL, "vh_conv: S8 sinks given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
+        if (a.tail_f32 && pc != 1)
+            return vh_fail(VH_EINVAL, "vh_conv: tail_f32 given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
         if (pc == 1) {
             if (pwgs >= (1LL << 31)) return vh_fail(VH_EINVAL, "vh_conv: grid too large");
             k.ksplit = 1; k.scratch = nullptr; k.korder = 1; k.stagger = vh_knob(VH_KNOB_CONV_PATCH_DELAY); k.dbg = vh_debug_ptr();

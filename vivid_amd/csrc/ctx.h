@@ -53,7 +53,9 @@ enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATT
        VH_KNOB_FUSE_CONCAT = 13,     // vh_net walk: decoder concat inputs written by their producers (vh_s8_sink): 0 never, 1 the x half only, 2 both halves
        VH_KNOB_CONV_PATCH96 = 14,    // 1 (default): Cout = 192 layers take the patch kernel as two 96-channel blocks; 0: the 256x192 tile of conv_x3_glds (A/B)
        VH_KNOB_CONV_PATCH_TAIL = 15, // conv_x3_patch with a tail segment: 2 (default) the wave-private register-staged tail, 1 the LDS-DMA staged one (64-channel blocks; A/B)
-       VH_NUM_KNOBS = 16 };
+       VH_KNOB_CONV_TAIL_F32 = 16,   // vh_conv_args.tail_f32 launches: 1 (default) taken where the patch kernel takes tails, 0 never (vh_conv_takes_patch answers 0: callers
+                                     // fall back to the raw S8 form of vh_split), 2 also at Cout = 256 / 512 (ties on the S8 tail; A/B)
+       VH_NUM_KNOBS = 17 };
 int vh_knob(int id);
 // device buffer for the stamps of diagnostic builds (-DVH_CLOCK), set through the knobs "dbg_lo"/"dbg_hi"; null otherwise
 inline unsigned long long* vh_debug_ptr() {

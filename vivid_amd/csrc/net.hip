@@ -217,6 +217,7 @@ struct ConvOpt {
     int up = 0, epi = VH_EPI_STORE; const float* cvec = nullptr; int cvec_ld = 0; const Buf* res = nullptr; int res_up = 0;
     float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr; bool s8_only = false, also_s8 = false; const vh_qkv_epilogue* qkv = nullptr;
     const Buf* src1 = nullptr;        // S8 second source: the 1-tap tail segment of a fused conv_res1 + conv_skip
+    const Buf* tail0 = nullptr; const Buf* tail1 = nullptr; float tsc0 = 1.f, tsc1 = 0.f;     // ... or the fp32 tensors x, skip themselves with their mp_cat weights (vh_conv_args.tail_f32)
     const Buf* res_scale = nullptr;   // per-pixel factor of the residual
     int sink_j = -1, sink_half = 0;   // this result is half 0 (x) / 1 (skip) of decoder block sink_j's concat input: written as S8 by this launch if it takes the patch kernel
     bool fp32_optional = false;       // ... and nothing else reads its fp32 form
@@ -230,7 +231,8 @@ std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, i
     bool sunk = false;
     if (o.sink_j >= 0 && !o.qkv) {
         vh_conv_args q{};
-        q.src0 = reinterpret_cast<const float*>(16); q.src1 = o.src1 ? reinterpret_cast<const float*>(16) : nullptr; q.c0 = src.c; q.c1 = o.src1 ? o.src1->c : 0;
+        q.src0 = reinterpret_cast<const float*>(16); q.src1 = (o.src1 || o.tail0) ? reinterpret_cast<const float*>(16) : nullptr; q.c0 = src.c;
+        q.c1 = o.tail0 ? o.tail0->c : o.src1 ? o.src1->c : 0; q.tail_f32 = o.tail0 ? 1 : 0; q.src2 = o.tail1 ? reinterpret_cast<const float*>(16) : nullptr; q.c2 = o.tail1 ? o.tail1->c : 0;
         q.rows = rows; q.h = h; q.w = w; q.up = o.up; q.taps = W.taps; q.cout = W.cout; q.prec = VH_PREC_BF16X3; q.kernel = VH_CONV_GLDS256; q.epi = o.epi; q.res_up = o.res_up;
         if (vh_conv_takes_patch(&q) == 1) {
             CatState& st = n->cat.at(o.sink_j);
@@ -249,6 +251,10 @@ std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, i
     if (!o.s8_only && !o.qkv && !skip_fp32) { if (o.out) out = *o.out; else out = alloc(n, rows, h, w, W.cout); }
     vh_conv_args a{};
     a.src0 = ptr(n, src); a.src1 = o.src1 ? ptr(n, *o.src1) : nullptr; a.c0 = src.c; a.c1 = o.src1 ? o.src1->c : 0; a.scale0 = 1.f; a.scale1 = 1.f;
+    if (o.tail0) {
+        a.tail_f32 = 1; a.src1 = ptr(n, *o.tail0); a.c1 = o.tail0->c; a.scale1 = o.tsc0;
+        if (o.tail1) { a.src2 = ptr(n, *o.tail1); a.c2 = o.tail1->c; a.scale2 = o.tsc1; }
+    }
     a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = VH_PRO_NONE;
     a.wt = W.wt; a.cin_pad = W.cin_pad; a.k_pad = W.k_pad; a.zeros = n->zeros; a.zeros_bytes = ZEROS_FLOATS * 4; a.cout = W.cout;
     a.scratch = n->scratch; a.scratch_floats = SCRATCH_FLOATS;
@@ -357,6 +363,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         const long long npix_in = up ? npix / 4 : npix;
         const int Rin = up ? R / 2 : R;
         std::pair<Buf, Buf> cs;
+        bool tail32 = false;
         CatState* st = (cat_j >= 0 && skip) ? &n->cat.at(cat_j) : nullptr;
         if (st && (st->x_done || st->skip_done)) {
             // at least one half of mp_silu(mp_cat(x, skip)) was written by its producer (vh_s8_sink); vh_split fills in the other, if any
@@ -364,7 +371,16 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
             if (!st->skip_done) split_half(n, *skip, st->sc1, *st, st->Na, npix_in);
             cs = {st->cs, st->craw};
         } else {
-            cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, has_skip_conv);
+            // the fused conv_res1 + conv_skip launch reads x and skip as fp32 where the library's size rule gives it the patch-resident kernel
+            // (vh_conv_args.tail_f32): vh_split then writes the mp_silu form only (engine.Engine._tail_f32)
+            if (has_skip_conv && !up && x.c % 32 == 0 && (!skip || skip->c % 32 == 0)) {
+                vh_conv_args q{};
+                q.src0 = q.src1 = reinterpret_cast<const float*>(16); q.out = reinterpret_cast<float*>(16); q.c0 = C; q.c1 = x.c; q.tail_f32 = 1;
+                q.src2 = skip ? reinterpret_cast<const float*>(16) : nullptr; q.c2 = skip ? skip->c : 0;
+                q.rows = rows; q.h = R; q.w = R; q.up = 0; q.taps = 9; q.cout = C; q.prec = VH_PREC_BF16X3; q.kernel = VH_CONV_GLDS256; q.epi = VH_EPI_STORE;
+                tail32 = vh_conv_takes_patch(&q) == 1;
+            }
+            cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, has_skip_conv && !tail32);
         }
         ConvOpt o0; o0.up = up; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
         Buf y = conv(n, cs.first, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
@@ -372,7 +388,8 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         std::pair<Buf, Buf> r;
         if (has_skip_conv) {
             // conv_res1 + conv_skip as one GEMM: the raw concat is the 1-tap tail segment, ta / tb are folded into the weights
-            ConvOpt o1; o1.epi = VH_EPI_STORE; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8; o1.src1 = &cs.second;
+            ConvOpt o1; o1.epi = VH_EPI_STORE; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+            if (tail32) { o1.tail0 = &x; o1.tail1 = skip; o1.tsc0 = sc0; o1.tsc1 = skip ? sc1 : 0.f; } else o1.src1 = &cs.second;
             o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
             r = conv(n, y, n->W.at(p + "conv_res1+skip"), rows, R, R, o1);
             release(n, cs.second);

@@ -250,6 +250,16 @@ class Engine:
         return (self.x3 and self.glds and self.fuse_skip and b.kind == "block" and b.flavor == "dec" and b.cin != b.cout
                 and b.cout % 32 == 0 and b.cin % 32 == 0)
 
+    def _tail_f32(self, b: BlockSpec, rows: int, srcs) -> bool:
+        """Does the fused conv_res1 + conv_skip launch of decoder block b read its tail segment from the fp32 tensors x and skip themselves
+        (vh_conv_args.tail_f32)?  The library answers (vh_conv_takes_patch: the patch-resident kernel's size rule); then vh_split writes the
+        mp_silu form of the concat only - a third of its bytes less."""
+        if not (self._fused_skip(b) and all(s_.shape[-1] % 32 == 0 for s_, _ in srcs)):
+            return False
+        q = L.ConvArgs(src0=16, src1=16, c0=b.cout, c1=srcs[0][0].shape[-1], src2=16 if len(srcs) > 1 else None, c2=srcs[1][0].shape[-1] if len(srcs) > 1 else 0,
+                       tail_f32=1, rows=rows, h=b.res, w=b.res, up=0, taps=9, cout=b.cout, prec=1, kernel=1, epi=L_EPI_STORE, out=16)
+        return L.lib().vh_conv_takes_patch(C.byref(q)) == 1
+
     def _prep_fused_res1_skip(self, p: str, b: BlockSpec):
         ta, tb = self._mp_sum_coeffs(self.cfg.res_balance)
         w1, ws = self._params[p + "conv_res1.weight"], self._params[p + "conv_skip.weight"]
@@ -342,8 +352,9 @@ class Engine:
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
               cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0, res_scale: Optional[Buf] = None,
               ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False, qkv=None,
-              sink_plan: Optional[Tuple[int, str]] = None, fp32_optional=False):
-        """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  s8_only: the result is written only as S8;
+              sink_plan: Optional[Tuple[int, str]] = None, fp32_optional=False, tail_f32=False):
+        """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  tail_f32: srcs[1:] are the fp32 tensors of the 1-tap tail segment with their mp_cat weights
+        (vh_conv_args.tail_f32: the bf16 split happens while the tail is staged; no raw S8 concat exists).  s8_only: the result is written only as S8;
         also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned.
         qkv (L.QkvEpilogue): the result goes straight into attention operand buffers (VH_EPI_QKV); nothing is returned."""
         out_s8 = None
@@ -351,12 +362,15 @@ class Engine:
             epi = L_EPI_QKV
         s0, sc0 = srcs[0]
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
+        s2, sc2 = srcs[2] if len(srcs) > 2 else (None, 0.0)
+        assert s2 is None or tail_f32
         # sink_plan = (dec block index, "x" | "skip"): this result is one half of that block's concat input.  If the launch takes the patch-resident
         # kernel (the library's own rule: vh_conv_takes_patch), it writes the S8 forms itself (fp32_optional: and nothing else reads the fp32 form)
         sinks = None
         if sink_plan is not None and prec and self.glds and self.hook is None and qkv is None:
             q = L.ConvArgs(src0=16, src1=16 if s1 is not None else None, c0=s0.shape[-1], c1=s1.shape[-1] if s1 is not None else 0, rows=rows, h=h, w=w,
-                           up=up, taps=W.taps, cout=W.cout, prec=prec, kernel=1, epi=epi, res_up=res_up)
+                           up=up, taps=W.taps, cout=W.cout, prec=prec, kernel=1, epi=epi, res_up=res_up, tail_f32=int(tail_f32),
+                           src2=16 if s2 is not None else None, c2=s2.shape[-1] if s2 is not None else 0)
             if L.lib().vh_conv_takes_patch(C.byref(q)) == 1:
                 sinks = self._cat_sinks(*sink_plan)
         skip_fp32 = sinks is not None and fp32_optional and not also_s8 and not s8_only
@@ -377,11 +391,12 @@ class Engine:
                        res=res.ptr if res is not None else None, res_up=res_up, res_scale=res_scale.ptr if res_scale is not None else None,
                        ta=ta, tb=tb, clip=clip,
                        qkv=C.addressof(qkv) if qkv is not None else None,
-                       stagger=self.conv_stagger if (prec and self.glds) else 0)
+                       stagger=self.conv_stagger if (prec and self.glds) else 0,
+                       tail_f32=int(tail_f32), src2=s2.ptr if s2 is not None else None, c2=s2.shape[-1] if s2 is not None else 0, scale2=sc2)
         for i, (buf, ct, off, scale, silu) in enumerate(sinks or []):
             a.sink[i] = L.S8Sink(ptr=buf.ptr, c_total=ct, c_off=off, scale=scale, silu=silu)
-        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}"
-                   + (f" sinks={len(sinks)}" if sinks else ""))
+        self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1 + a.c2} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}"
+                   + (f" sinks={len(sinks)}" if sinks else "") + (" tail=fp32" if tail_f32 else ""))
         if skip_fp32:
             return Ghost((rows, h, w, W.cout))
         if qkv is not None:
@@ -557,7 +572,7 @@ class Engine:
                 srcs = [(x, Cc / math.sqrt(Na) * (1 - t)), (skip, Cc / math.sqrt(Nb) * t)]
             else:
                 srcs = [(x, 1.0)]
-            craw = None
+            craw, tail32 = None, False
             st = self._cat.get(cat_j) if (cat_j is not None and skip is not None) else None
             if x3 and st is not None and (st["x_done"] or st["skip_done"]):
                 # at least one half of mp_silu(mp_cat(x, skip)) was written by its producer (vh_s8_sink); vh_split fills in the other, if any
@@ -567,8 +582,9 @@ class Engine:
                     self._split_half(skip, st["sc1"], st, st["Na"])
                 cs, craw = st["cs"], st["craw"]
             elif x3:
-                # mp_silu(mp_cat(...)) once per element as S8; the raw split is conv_skip's input
-                if has_skip_conv:
+                # mp_silu(mp_cat(...)) once per element as S8; the raw split is conv_skip's input - unless the fused launch reads x and skip as fp32
+                tail32 = has_skip_conv and not up and self._tail_f32(b, rows, srcs)
+                if has_skip_conv and not tail32:
                     cs, craw = self._split(srcs, L_PRO_SILU, raw_too=True)
                 else:
                     cs = self._split(srcs, L_PRO_SILU)
@@ -581,8 +597,8 @@ class Engine:
                                epi=L_EPI_SCALE_SILU, cvec=cv)
             if has_skip_conv and x3 and self._fused_skip(b):
                 # conv_res1 + conv_skip as one GEMM: the raw concat enters as the 1-tap tail of the K loop, ta / tb are in the weights
-                r = self._conv([(y, 1.0), (craw, 1.0)], self.W[p + "conv_res1+skip"], rows, R, R, epi=L_EPI_STORE, clip=clip_res, prec=1,
-                               also_s8=res1_s8 or fin_s8, sink_plan=out_sink, fp32_optional=fp32_optional)
+                r = self._conv([(y, 1.0)] + (list(srcs) if tail32 else [(craw, 1.0)]), self.W[p + "conv_res1+skip"], rows, R, R, epi=L_EPI_STORE, clip=clip_res,
+                               prec=1, also_s8=res1_s8 or fin_s8, sink_plan=out_sink, fp32_optional=fp32_optional, tail_f32=tail32)
                 self._free(craw)
                 xsk = None
             else:
