@@ -302,7 +302,7 @@ Buf resample(vh_net* n, const Buf& x, int rows, int h, int w, bool up) {
 // Block.forward :165-206 / XAttnBlock.forward :251-315 (bf16x3 path of engine.Engine._block)
 std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, int rows, const Buf& x, const Buf* skip, const Buf& cvec_all,
                           const vh_net::EmbW& emb, const Feat* feat, int nsrc, float n_zero, bool want_s8, int cat_j = -1, int out_sink_j = -1, int out_sink_half = 0,
-                          bool fp32_optional = false) {
+                          bool fp32_optional = false, bool s8_final = false) {
     const vh_net_config& cfg = n->cfg;
     const std::string p = prefix + (b.dec ? "dec." : "enc.") + b.name + ".";
     const int R = b.res, C = b.cout, D = b.heads ? C / b.heads : 0;
@@ -312,6 +312,8 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
     const float clip = cfg.clip_act > 0.0 ? (float)cfg.clip_act : 0.f, clip_res = b.heads ? 0.f : clip;
     const bool has_skip_conv = b.cin != b.cout;
     const bool res1_s8 = b.heads > 0, fin_s8 = want_s8 && !b.heads;
+    // the UNet's last block: out_conv is its only reader and reads S8 - conv_res1 writes that form alone (engine.Engine._block: fin_only)
+    const bool fin_only = s8_final && !b.heads && b.dec;
     if (b.heads) { out_sink_j = -1; fp32_optional = false; }      // (the block's last op is attn_proj, a 1x1 convolution: no sinks there)
     const long long npix = (long long)rows * R * R;
     Buf out, r_s8, out_s8;
@@ -388,20 +390,21 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         std::pair<Buf, Buf> r;
         if (has_skip_conv) {
             // conv_res1 + conv_skip as one GEMM: the raw concat is the 1-tap tail segment, ta / tb are folded into the weights
-            ConvOpt o1; o1.epi = VH_EPI_STORE; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
+            ConvOpt o1; o1.epi = VH_EPI_STORE; o1.clip = clip_res; o1.also_s8 = (res1_s8 || fin_s8) && !fin_only; o1.s8_only = fin_only;
             if (tail32) { o1.tail0 = &x; o1.tail1 = skip; o1.tsc0 = sc0; o1.tsc1 = skip ? sc1 : 0.f; } else o1.src1 = &cs.second;
             o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
             r = conv(n, y, n->W.at(p + "conv_res1+skip"), rows, R, R, o1);
             release(n, cs.second);
         } else {
-            ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = &x; o1.res_up = up; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = res1_s8 || fin_s8;
-            o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
+            ConvOpt o1; o1.epi = VH_EPI_MPSUM; o1.res = &x; o1.res_up = up; o1.ta = ta; o1.tb = tb; o1.clip = clip_res; o1.also_s8 = (res1_s8 || fin_s8) && !fin_only;
+            o1.s8_only = fin_only; o1.sink_j = out_sink_j; o1.sink_half = out_sink_half; o1.fp32_optional = fp32_optional;
             r = conv(n, y, n->W.at(p + "conv_res1.weight"), rows, R, R, o1);
         }
         release(n, y); release(n, xup);
         out = r.first; r_s8 = r.second;
+        if (fin_only) out = ghost(C);
     }
-    if (fin_s8) out_s8 = r_s8;
+    if (fin_s8 || fin_only) out_s8 = r_s8;
     if (b.heads) {
         const int S = R * R;
         const bool use_feat = b.xattn && feat != nullptr;
@@ -598,7 +601,7 @@ Buf embedding(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net
 
 // UNetEncoder.forward :536-570 (collect) / XAttnUNet.forward :483-518
 Buf run_unet(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net::EmbW& emb, int rows, Buf x_in, const Buf& cvec,
-             const std::vector<Feat>* feats, bool collect, float n_zero, int nsrc, std::vector<Feat>* out_feats) {
+             const std::vector<Feat>* feats, bool collect, float n_zero, int nsrc, std::vector<Feat>* out_feats, Buf* last_s8 = nullptr) {
     std::vector<Buf> skips;
     size_t fi = 0;
     Buf x = x_in;
@@ -674,8 +677,10 @@ Buf run_unet(vh_net* n, const std::string& prefix, const Spec& sp, const vh_net:
         // this block's result is the x half of the NEXT block's concat input, and nothing else reads it
         const Block* nb = (j + 1 < (int)sp.dec.size() && sp.dec[j + 1].live) ? &sp.dec[j + 1] : nullptr;
         const bool xs_ok = nb && nb->takes_skip && n->cat.count(j + 1) && n->cat.at(j + 1).ok && !b.heads;
+        const bool s8_final = !collect && !nb && last_s8 && sp.out_channels > 0;
         auto r = n->fp32 ? std::pair<Buf, Buf>{block_f32(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero), Buf{}}
-                         : block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0, n->cat.count(j) ? j : -1, xs_ok ? j + 1 : -1, 0, xs_ok);
+                         : block(n, prefix, b, rows, x, sk, cvec, emb, f, nsrc, n_zero, collect && b.heads > 0, n->cat.count(j) ? j : -1, xs_ok ? j + 1 : -1, 0, xs_ok, s8_final);
+        if (s8_final && !r.first.ok() && r.second.ok()) *last_s8 = r.second;
         if (x.ok() && !kept(x) && !in_skips(x)) release(n, x);
         if (sk && skip.ok() && !kept(skip) && !in_skips(skip) && skip.off != x.off) release(n, skip);
         if (collect && b.heads > 0) out_feats->push_back(Feat{r.first, r.second});
@@ -774,13 +779,14 @@ void walk(vh_net* n, int B, Program& pr, int mode, const std::vector<Feat>* ext)
         release(n, dgrid);
         Buf cvec = embedding(n, "unet.", n->unet, n->embU, B, pr.sigma, rm, 1.f, pr.geometry, cfg.target_label_dim);
         const float n_zero = have_feats ? 0.f : (float)nsrc;
-        Buf last = run_unet(n, "unet.", n->unet, n->embU, B, xin, cvec, have_feats ? use : nullptr, false, n_zero, nsrc, nullptr);
+        Buf last8;
+        Buf last = run_unet(n, "unet.", n->unet, n->embU, B, xin, cvec, have_feats ? use : nullptr, false, n_zero, nsrc, nullptr, &last8);
         Buf F;
         if (n->fp32) F = conv_f32(n, last, n->W.at("unet.out_conv.weight"), B, R, R, ConvF{});
         else {
-            auto ls8 = split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false);
-            F = conv(n, ls8.first, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
-            release(n, ls8.first);
+            Buf ls8 = last8.ok() ? last8 : split(n, last, 1.f, nullptr, 1.f, (long long)B * R * R, B, R, R, VH_PRO_NONE, false).first;
+            F = conv(n, ls8, n->W.at("unet.out_conv.weight"), B, R, R, ConvOpt{}).first;
+            release(n, ls8);
         }
         release(n, last); release(n, cvec);
         vh_precond_out_args po{}; po.x = ptr(n, pr.x); po.row_mul = rm; po.f = ptr(n, F); po.fc = F.c; po.sigma = ptr(n, pr.sigma); po.sigma_data = (float)cfg.sigma_data;

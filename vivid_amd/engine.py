@@ -500,7 +500,7 @@ class Engine:
                cvec_all: Buf, cols: Dict[str, int], total_cols: int,
                feat: Optional[Buf], feat_s8: Optional[Buf], n_zero: float, want_s8: bool = False,
                cat_j: Optional[int] = None, out_sink: Optional[Tuple[int, str]] = None, fp32_optional: bool = False,
-               kv_pre: Optional[Tuple[Buf, Buf]] = None):
+               kv_pre: Optional[Tuple[Buf, Buf]] = None, s8_final: bool = False):
         """Block.forward :165-206 / XAttnBlock.forward :251-315.  x is the block input (before
         resampling); returns (block output fp32, its S8 copy or None).  Neither x nor skip is released here.
         In bf16x3 mode every conv reads an S8 (bf16 hi/lo) tensor written by the op that produced it."""
@@ -520,6 +520,8 @@ class Engine:
         out_s8 = None
         res1_s8 = bool(b.heads) and ax3                 # conv_res1's result also feeds attn_qkv -> S8 copy
         fin_s8 = want_s8 and x3 and not b.heads         # no attention: conv_res1's result is the block output
+        # the UNet's last block: out_conv is its only reader and reads S8 - conv_res1 writes that form alone (no fp32 tensor, no vh_split pass)
+        fin_only = s8_final and x3 and not b.heads and b.flavor == "dec" and self.hook is None
         if b.heads or not x3:
             out_sink, fp32_optional = None, False       # (the block's last op is attn_proj, a 1x1 convolution: no sinks there)
         if b.flavor == "enc":
@@ -598,7 +600,8 @@ class Engine:
             if has_skip_conv and x3 and self._fused_skip(b):
                 # conv_res1 + conv_skip as one GEMM: the raw concat enters as the 1-tap tail of the K loop, ta / tb are in the weights
                 r = self._conv([(y, 1.0)] + (list(srcs) if tail32 else [(craw, 1.0)]), self.W[p + "conv_res1+skip"], rows, R, R, epi=L_EPI_STORE, clip=clip_res,
-                               prec=1, also_s8=res1_s8 or fin_s8, sink_plan=out_sink, fp32_optional=fp32_optional, tail_f32=tail32)
+                               prec=1, also_s8=(res1_s8 or fin_s8) and not fin_only, s8_only=fin_only, sink_plan=out_sink, fp32_optional=fp32_optional,
+                               tail_f32=tail32)
                 self._free(craw)
                 xsk = None
             else:
@@ -613,16 +616,18 @@ class Engine:
                     assert skip is None
                     xsk, res, res_up = None, x, up
                 r = self._conv([(y, 1.0)], self.W[p + "conv_res1.weight"], rows, R, R, epi=L_EPI_MPSUM, res=res,
-                               res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=res1_s8 or fin_s8, sink_plan=out_sink,
-                               fp32_optional=fp32_optional)
+                               res_up=res_up, ta=ta, tb=tb, clip=clip_res, prec=P1, also_s8=(res1_s8 or fin_s8) and not fin_only, s8_only=fin_only,
+                               sink_plan=out_sink, fp32_optional=fp32_optional)
             self._free(y)
             self._free(xsk)
             self._free(xup)
-        if res1_s8 or fin_s8:
+        if fin_only:
+            out, r_s8 = Ghost((rows, R, R, C)), r
+        elif res1_s8 or fin_s8:
             out, r_s8 = r
         else:
             out, r_s8 = r, None
-        if fin_s8:
+        if fin_s8 or fin_only:
             out_s8 = r_s8
         if not isinstance(out, Ghost):
             self._tap(p + "res", out)
@@ -773,6 +778,8 @@ class Engine:
                     skips[-1] = Ghost(x.shape)
             skips.append(nx)
             x = nx
+        n_live = sum(1 for b in spec.dec if b.live) if (spec.dec and spec.dec[0].live) else 0
+        x8 = None
         for j, b in enumerate(spec.dec):
             if not b.live:
                 break
@@ -783,7 +790,9 @@ class Engine:
             xs_ok = nb_ is not None and nb_.takes_skip and (j + 1) in self._cat and self._cat[j + 1]["ok"] and not b.heads
             nx, nx8 = self._block(prefix, "dec", b, rows, x, skip, cvec, cols, total, f32, f8, n_zero,
                                   want_s8=collect and b.heads > 0, cat_j=j if j in self._cat else None,
-                                  out_sink=(j + 1, "x") if xs_ok else None, fp32_optional=xs_ok, kv_pre=fkv)
+                                  out_sink=(j + 1, "x") if xs_ok else None, fp32_optional=xs_ok, kv_pre=fkv,
+                                  s8_final=not collect and j == n_live - 1 and spec.out_channels > 0)
+            x8 = nx8 if isinstance(nx, Ghost) and j == n_live - 1 else None
             for old in (x, skip):
                 if old is not None and not kept(old) and all(old is not s_ for s_ in skips):
                     self._free(old)
@@ -793,7 +802,7 @@ class Engine:
         for s_ in skips:                              # skips the trimmed encoder-decoder never consumed
             if not kept(s_) and s_ is not x:
                 self._free(s_)
-        return x, out_feats
+        return x, out_feats, x8
 
     # ------------------------------------------------------------------ program construction
     def program(self, mode: str, B: int, has_cond: bool, want_logvar: bool, fill=None, slot: int = 0) -> Program:
@@ -912,7 +921,7 @@ class Engine:
             sgrid = None
             cvec, _ = self._embedding("encoder.", spec, rows_all, io["sigma"], 1, 0.0 if cfg.no_time_enc else 1.0,
                                       io["geometry"], cfg.source_label_dim)
-            last, feats = self._run_unet("encoder.", spec, rows_all, xin, cvec, None, True, 0.0)
+            last, feats, _ = self._run_unet("encoder.", spec, rows_all, xin, cvec, None, True, 0.0)
             if all(last is not f[0] for f in feats):
                 self._free(last)
             self._free(cvec)
@@ -937,9 +946,9 @@ class Engine:
             label_dim = cfg.target_label_dim
             cvec, _ = self._embedding("unet.", spec, B, io["sigma"], rm, 1.0, io["geometry"], label_dim)
             n_zero = float(self.nsrc) if (mode == "uncond") else 0.0
-            last, _ = self._run_unet("unet.", spec, B, xin, cvec, feats if mode != "uncond" else None, False, n_zero)
+            last, _, last8 = self._run_unet("unet.", spec, B, xin, cvec, feats if mode != "uncond" else None, False, n_zero)
             if self.x3:
-                ls8 = self._split([(last, 1.0)], 0)
+                ls8 = last8 if last8 is not None else self._split([(last, 1.0)], 0)
                 F = self._conv([(ls8, 1.0)], self.W["unet.out_conv.weight"], B, R, R, prec=1)
                 self._free(ls8)
             else:
