@@ -203,7 +203,7 @@ typedef struct {
                                               VH_TILE_512x128, VH_TILE_512x64 and VH_TILE_256x64 (need cout <= 64; the latter runs two
                                               workgroups per CU), VH_TILE_256x192 (3x3 only).  A forced shape disables split-K unless
                                               the grid is small; every shape computes the same sums in the same order.
-                                              VH_TILE_PATCH16: the patch-resident kernel (conv_patch.hip) - 3x3, no `up`, cout % 32 == 0 (or cout <= 16 with a plain fp32 store): one
+                                              VH_TILE_PATCH16: the patch-resident kernel (conv_patch.hip) - 3x3, cout % 32 == 0 (or cout <= 16 with a plain fp32 store): one
                                               workgroup per 16x16-pixel output tile of one image, its (16+2)^2-pixel input patch staged once per
                                               32-channel chunk and read in place by the nine taps; chunk-major K order (sums agree with the other
                                               tiles to fp32 rounding). */

@@ -246,6 +246,38 @@ def test_conv_patch_kernel_shapes(ctx, rows, h, w, cin, epi):
         assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5, tile
 
 
+@pytest.mark.parametrize("rows,h,w,cin,cout", [(2, 48, 32, 64, 64), (1, 40, 24, 128, 128), (1, 64, 64, 192, 192), (2, 256, 256, 64, 64)])
+def test_conv_patch_kernel_up(ctx, rows, h, w, cin, cout):
+    """`up` on the patch-resident kernel: conv_res0 of an `up` block reads resample(x, mode='up') (training/models.py:60-61, :167) - patch pixel
+    (y, x) of the upsampled image is source pixel (y>>1, x>>1), zero padding at the UPSAMPLED border; h x w is the output size.  Against the
+    oracle's mp_conv(resample(x)) with the cvec + mp_silu epilogue of that layer, forced (tile 8), by the size rule, and on a conv_x3_glds tile."""
+    from vivid_amd import _lib as L
+    g = torch.Generator().manual_seed(rows + h + w + cin)
+    xlow = torch.randn(rows, cin, h // 2, w // 2, generator=g)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g)
+    cv = torch.randn(rows, cout, generator=g) * 0.3 + 1
+    ref = R.mp_silu(R.mp_conv(R.resample(xlow, "up"), wgt) * cv[:, :, None, None])
+    Ml, M = rows * (h // 2) * (w // 2), rows * h * w
+    xd = _nhwc(xlow).cuda()
+    xs8 = torch.empty(Ml * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xd.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=Ml, c_pad=cin, out=xs8.data_ptr(), out_raw=None))
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+    cd = cv.cuda()
+    outs = {}
+    for tile in (8, 0, 1):
+        out = torch.full((M, cout), float("nan"), device="cuda")
+        o8 = torch.empty(M * cout, device="cuda")
+        ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=1, taps=9, pro=0,
+                                      wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0,
+                                      cout=cout, out=out.data_ptr(), out_s8=o8.data_ptr(), out_s8_c=cout, prec=1, kernel=1, epi=1, cvec=cd.data_ptr(),
+                                      cvec_ld=cout, res=None, res_up=0, ta=0, tb=0, clip=0, korder=0, tile=tile))
+        torch.cuda.synchronize()
+        assert rel_l2(out.cpu().view(rows, h, w, cout), _nhwc(ref)) < 3e-5, tile
+        assert rel_l2(_s8_decode(o8, (rows, h, w, cout)).cpu(), _nhwc(ref)) < 3e-5, tile
+        outs[tile] = out
+    assert rel_l2(outs[8].cpu(), outs[1].cpu()) < 2e-6
+
+
 @pytest.mark.parametrize("rows,h,w,cin,cout", [(2, 40, 17, 64, 3), (1, 32, 48, 128, 3), (1, 16, 16, 32, 16), (3, 256, 256, 64, 3)])
 def test_conv_patch_kernel_narrow_output(ctx, rows, h, w, cin, cout):
     """conv_x3_patch's 16-column instantiation (Cout <= 16, plain store: UNet.out_conv, training/models.py:480 - 3 channels with out_gain folded

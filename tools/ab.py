@@ -132,7 +132,7 @@ def main():
             tailf = knobs.pop("tailf32", 0) if c1 else 0    # 1: the tail segment read from the fp32 tensor (vh_conv_args.tail_f32)
             s8mode = knobs.pop("s8", 0)                     # 0: fp32 output, 1: S8 only, 2: both
             o8 = torch.empty(M * cout, device="cuda") if s8mode else None
-            a = L.ConvArgs(src0=s8.data_ptr(), src1=(x1.data_ptr() if tailf else s81.data_ptr()) if c1 else None, tail_f32=tailf, c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=taps, pro=0,
+            a = L.ConvArgs(src0=s8.data_ptr(), src1=(x1.data_ptr() if tailf else s81.data_ptr()) if c1 else None, tail_f32=tailf, c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=knobs.pop("up", 0), taps=taps, pro=0,
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
                            scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if (s8mode != 1 and epi != 3) else None, out_s8=o8.data_ptr() if o8 is not None else None,
                            out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,

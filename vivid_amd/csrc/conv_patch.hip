@@ -226,7 +226,10 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
     // once per nine K-tiles) instead of held across the K loop - the loop has no registers to spare (<= 128 for two workgroups per CU).
     const float4* src4 = reinterpret_cast<const float4*>(a.src0);
     const unsigned cu4 = (unsigned)(a.c0 >> 2);                        // 16-byte units per pixel
-    const unsigned img_off = (unsigned)img * (unsigned)a.HW;
+    // `up` (resample(x, mode="up") with the default [1,1] filter fused into the loader, training/models.py:60-61, :167): patch pixel (yy, xx) of the
+    // upsampled image is source pixel (yy>>1, xx>>1) of the half-size tensor; zero padding applies at the UPSAMPLED border
+    const int Ws = a.up ? (a.w >> 1) : a.w;
+    const unsigned img_off = (unsigned)img * (unsigned)(a.up ? (a.HW >> 2) : a.HW);
     auto piece_src = [&](int j, unsigned cu, int tq) __attribute__((always_inline)) -> const float4* {
         // tq == threadIdx.x, passed through an opaque copy by the callers inside the K loop: otherwise hipcc hoists this whole computation
         // out of the loop and keeps its results live (LICM), which is exactly the register cost it is here to avoid
@@ -237,7 +240,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
         const bool inside = p < PPIX && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
         const int u = up ^ (p & 7), s8u = (u & 3) * 2 + (u >> 2);          // LDS unit order hl*4 + chunk -> S8 order chunk*2 + hl
         // 32-bit offsets in 16-byte units (the dispatcher checks M * c0 / 4 < 2^32)
-        return inside ? src4 + (size_t)((img_off + (unsigned)(yy * a.w + xx)) * cu4 + (unsigned)s8u + cu) : zp;
+        const int sy = a.up ? (yy >> 1) : yy, sx = a.up ? (xx >> 1) : xx;
+        return inside ? src4 + (size_t)((img_off + (unsigned)(sy * Ws + sx)) * cu4 + (unsigned)s8u + cu) : zp;
     };
     unsigned ldsP_w = 0, ldsB_w = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -633,8 +637,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
 int vh_diag_conv_patch() { return VH_DIAG_FLAG; }
 
-// Launch of the patch-resident kernel (arguments validated by vh_conv / chosen by vh_conv_x3_glds_dispatch): 3x3, no `up`, cout % 32 == 0,
-// epilogue STORE / SCALE_SILU / MPSUM without res_up.  One workgroup per 16x16 output tile per image and block of 64 (with a tail segment)
+// Launch of the patch-resident kernel (arguments validated by vh_conv / chosen by vh_conv_x3_glds_dispatch): 3x3 (with or without `up`),
+// cout % 32 == 0 or <= 16, epilogue STORE / SCALE_SILU / MPSUM.  One workgroup per 16x16 output tile per image and block of 64 (with a tail segment)
 // or 128 output channels.
 void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
     k.ptx = (k.w + PT - 1) / PT;

@@ -634,7 +634,7 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s);      // conv_patch
 int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out) {
     // (the kernel addresses its inputs through 32-bit offsets in 16-byte units: M * c / 4 < 2^32)
     const bool narrow = a.cout <= 16 && a.epi == VH_EPI_STORE && !a.src1 && !a.out_s8 && !a.sink[0].ptr && !a.sink[1].ptr && a.out;   // UNet.out_conv
-    const bool patch_ok = a.taps == 9 && !a.up && (a.cout % 32 == 0 || narrow) && a.epi != VH_EPI_QKV &&
+    const bool patch_ok = a.taps == 9 && (a.cout % 32 == 0 || narrow) && a.epi != VH_EPI_QKV &&
                           a.prec == VH_PREC_BF16X3 && a.kernel == VH_CONV_GLDS256 &&
                           (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0 && (double)M * a.c2 / 4.0 < 4294967296.0;
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
@@ -657,7 +657,8 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     const int mres = a.h < a.w ? a.h : a.w;
     // Narrow outputs (Cout <= 16: the 3-channel out_conv) take a 16-column instantiation: on the 256x64 tile the layer is bound by MFMAs on 61 idle columns
     const bool patch_rule = pwgs >= 256 && mres >= 32 && (narrow || a.cout == 64 || a.cout % 128 == 0 || (n96 && vh_knob(VH_KNOB_CONV_PATCH96) != 0)) &&
-                            (!tailp || a.cout <= 192 || (a.cout == 384 && wide_ok) || (a.tail_f32 && (tf == 2 || (a.cout == 256 && mres >= 64)))) && (mres >= 64 || a.cout <= 256);
+                            (!tailp || a.cout <= 192 || (a.cout == 384 && wide_ok) || (a.tail_f32 && (tf == 2 || (a.cout == 256 && mres >= 64)))) && (mres >= 64 || a.cout <= 256) &&
+                            (!a.up || a.cout <= 384);      // (`up`: +9..10 % at 128 channels, +5..8 % at 192, +1..3 % at 256 / 384, 0.99x at 512)
     return (patch_ok && (a.tile == VH_TILE_PATCH16 || (a.tile == VH_TILE_AUTO && (pknob > 0 || (pknob < 0 && patch_rule))))) ? 1 : 0;
 }
 
@@ -667,7 +668,7 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
     {
         long long pwgs = 0;
         const int pc = vh_conv_patch_choice(a, M, &pwgs);
-        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution without `up`, cout %% 32 == 0 or a plain fp32 store of cout <= 16 (got taps %d, up %d, cout %d)", a.taps, a.up, a.cout);
+        if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution with cout %% 32 == 0 or a plain fp32 store of cout <= 16 (got taps %d, cout %d)", a.taps, a.cout);
         if ((a.sink[0].ptr || a.sink[1].ptr) && pc != 1)
             return vh_fail(VH_EINVAL, "vh_conv: S8 sinks given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
         if (a.tail_f32 && pc != 1)
