@@ -216,6 +216,11 @@ typedef struct {
                                               bits vh_split would have written as the raw S8 form.  c1, c2 multiples of 32, k_pad = 9*cin_pad + c1 + c2.
                                               Patch-resident kernel only (ask vh_conv_takes_patch with these fields set; refused otherwise). */
     const float* src2; int c2; float scale2;
+    int src_f32;                           /* 1 (VH_PREC_BF16X3 + VH_CONV_GLDS256, 3x3, patch-resident kernel only - ask vh_conv_takes_patch): src0 (c0 channels, times
+                                              scale0) and optionally src1 (c1 channels, times scale1) are fp32 NHWC tensors forming the input as a channel concat,
+                                              `pro` applies - the meaning these fields have for VH_PREC_F32 - and the kernel makes the bf16 hi / lo split itself while
+                                              it stages each 32-channel chunk of its input patch: mp_silu(mp_cat(x, skip)) never exists in memory.  c0, c1
+                                              multiples of 32, cin_pad = c0 + c1; no tail segment. */
 } vh_conv_args;
 enum { VH_KORDER_AUTO = 0, VH_KORDER_TAP = 1, VH_KORDER_CHUNK = 2 };
 enum { VH_TILE_AUTO = 0, VH_TILE_256x128 = 1, VH_TILE_256x256 = 2, VH_TILE_512x128 = 3, VH_TILE_512x64 = 4, VH_TILE_256x64 = 5, VH_TILE_256x192 = 7,

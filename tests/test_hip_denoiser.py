@@ -319,11 +319,12 @@ def test_concat_fusion_modes_change_nothing(name):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-def test_fp32_tail_segment_changes_nothing():
-    """vh_conv_args.tail_f32 (knob "conv_tail_f32"): the fused conv_res1 + conv_skip launches of the decoder read mp_cat(x, skip) from the fp32
-    tensors and split it into bf16 hi / lo while staging, so vh_split writes one S8 form of the concat instead of two.  The staged bits are the
-    bits vh_split wrote: the reference's SR stage at full size (the smallest preset whose tails take the patch kernel) must give EQUAL outputs with
-    the knob on (default), off, and extended to the 256 / 512-channel blocks - in both walks."""
+def test_fp32_tail_and_fp32_sources_change_nothing():
+    """vh_conv_args.tail_f32 / src_f32 (knobs "conv_tail_f32", "conv_src_f32"): the decoder's fused conv_res1 + conv_skip launches read mp_cat(x, skip)
+    from the fp32 tensors and split it while staging their tail; conv_res0 stages its patches from the same fp32 tensors (mp_cat weights, mp_silu,
+    split in the kernel) - with both, a decoder block has no vh_split pass at all.  The staged bits are the bits vh_split wrote: the reference's SR
+    stage at full size (the smallest preset whose launches take the patch kernel) must give EQUAL outputs in every combination of the two knobs,
+    in both walks."""
     import vivid_amd
     from vivid_amd import _lib
     from vivid_amd.cnet import CNet
@@ -333,10 +334,11 @@ def test_fp32_tail_segment_changes_nothing():
     cond = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).cuda()
     x, sig = (torch.randn(2, 3, 256, 256, generator=g) * 2).cuda(), torch.full((2,), 1.3).cuda()
     sd = vivid_amd.synth_state_dict(cfg, seed=seed)
-    outs, tails = [], []
+    outs, counts = [], []
     try:
-        for mode in (1, 0, 2):
-            _lib.set_knob("conv_tail_f32", mode)
+        for tail, srcf in ((1, 1), (0, 0), (2, 1), (1, 0), (0, 1)):
+            _lib.set_knob("conv_tail_f32", tail)
+            _lib.set_knob("conv_src_f32", srcf)
             net = vivid_amd.NVPrecond.from_config(cfg, precision="bf16x3")
             net.load_state_dict(sd, strict=True)
             net.noisy_sr = 0.0
@@ -346,10 +348,14 @@ def test_fp32_tail_segment_changes_nothing():
             cn.load_state_dict(sd)
             b = cn(src, x, sig, geo, cond)
             torch.cuda.synchronize()
-            assert torch.equal(a, b), mode
+            assert torch.equal(a, b), (tail, srcf)
             outs.append(a)
-            tails.append(sum("tail=fp32" in d for d in list(net._engine.programs.values())[0].oplog))
+            log = list(net._engine.programs.values())[0].oplog
+            counts.append((sum("tail=fp32" in d for d in log), sum("src=fp32" in d for d in log), sum(d.startswith("split") for d in log)))
     finally:
         _lib.set_knob("conv_tail_f32", 1)
-    assert tails[1] == 0 and tails[0] > 0 and tails[2] >= tails[0], tails
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        _lib.set_knob("conv_src_f32", 1)
+    assert counts[1][0] == 0 and counts[1][1] == 0 and counts[0][0] > 0 and counts[0][1] > 0 and counts[2][0] >= counts[0][0], counts
+    assert counts[0][2] < counts[3][2] <= counts[1][2] and counts[0][2] < counts[4][2] <= counts[1][2], counts       # fewer vh_split launches with either, fewest with both
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)

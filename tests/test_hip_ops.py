@@ -460,6 +460,46 @@ def test_conv_fp32_tail_equals_s8_tail(ctx, cout, na, nb, cin, h, w):
         ctx.call("vh_conv", a)
 
 
+@pytest.mark.parametrize("cout,na,nb,h,w,up,pro", [(64, 64, 64, 40, 24, 0, 1), (128, 256, 128, 48, 32, 0, 1), (192, 192, 0, 32, 32, 1, 1), (256, 128, 128, 32, 48, 0, 0),
+                                                   (128, 128, 0, 64, 64, 1, 1), (64, 32, 0, 24, 40, 0, 1)])
+def test_conv_fp32_sources_equal_split_then_conv(ctx, cout, na, nb, h, w, up, pro):
+    """vh_conv_args.src_f32: the MAIN loop of the patch-resident kernel reads its input from the fp32 tensors (mp_cat weights, mp_silu and the bf16
+    hi / lo split applied while each 32-channel chunk of the patch is staged through registers) - conv_res0 of a decoder block without a vh_split
+    pass (training/models.py:78-84, :174-176).  Must be the SAME BITS as vh_split followed by the S8 convolution: one and two sources, every block
+    width, `up` (source pixel = patch pixel >> 1), with and without mp_silu, ragged tiles."""
+    from vivid_amd import _lib as L
+    rows = 2
+    g = torch.Generator().manual_seed(cout + na + nb + h + up)
+    hs, ws = (h // 2, w // 2) if up else (h, w)
+    Ms, M = rows * hs * ws, rows * h * w
+    xa = torch.randn(Ms, na, generator=g).cuda()
+    xb = torch.randn(Ms, nb, generator=g).cuda() if nb else None
+    sa, sb = 0.83, 1.21
+    cin = na + nb
+    xs8 = torch.empty(Ms * cin, device="cuda")
+    ctx.call("vh_split", L.SplitArgs(src0=xa.data_ptr(), src1=xb.data_ptr() if nb else None, c0=na, c1=nb, scale0=sa, scale1=sb, pro=pro, npix=Ms, c_pad=cin,
+                                     out=xs8.data_ptr(), out_raw=None))
+    wgt = torch.randn(cout, cin, 3, 3, generator=g)
+    wt, cin_pad, k_pad = _prep(ctx, wgt.cuda(), 9, split=2)
+    cv = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda()
+    common = dict(rows=rows, h=h, w=w, up=up, taps=9, wt=wt.data_ptr(), cin_pad=cin_pad, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0,
+                  cout=cout, out_s8_c=cout, prec=1, kernel=1, epi=1, cvec=cv.data_ptr(), cvec_ld=cout, tile=8)
+    o1, o2 = torch.empty(M, cout, device="cuda"), torch.full((M, cout), float("nan"), device="cuda")
+    s1, s2 = torch.empty(M * cout, device="cuda"), torch.empty(M * cout, device="cuda")
+    ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, out=o1.data_ptr(), out_s8=s1.data_ptr(), **common))
+    a = L.ConvArgs(src0=xa.data_ptr(), src1=xb.data_ptr() if nb else None, c0=na, c1=nb, scale0=sa, scale1=sb if nb else 1.0, pro=pro, src_f32=1, out=o2.data_ptr(),
+                   out_s8=s2.data_ptr(), **common)
+    assert L.lib().vh_conv_takes_patch(C.byref(a)) == 1
+    ctx.call("vh_conv", a)
+    torch.cuda.synchronize()
+    assert torch.isfinite(o1).all() and float(o1.abs().max()) > 0
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    a.tile = 1                                                              # conv_x3_glds stages by LDS-DMA: it cannot convert
+    assert L.lib().vh_conv_takes_patch(C.byref(a)) == 0
+    with pytest.raises(L.VividHipError, match="src_f32"):
+        ctx.call("vh_conv", a)
+
+
 def test_conv_tail_segment_is_validated(ctx):
     from vivid_amd import _lib as L
     base = dict(src0=_zeros(), src1=_zeros(), c0=32, c1=32, scale0=1.0, scale1=1.0, rows=1, h=8, w=8, pro=0, wt=_zeros(), cin_pad=32,

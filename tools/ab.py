@@ -22,7 +22,7 @@ import torch  # noqa: E402
 from vivid_amd import _lib as L  # noqa: E402
 
 
-KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0, "conv_patch": -1, "conv_patch_delay": 0, "fuse_concat": 0, "conv_patch96": 1, "conv_patch_tail": 2, "conv_tail_f32": 1}
+KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0, "conv_patch": -1, "conv_patch_delay": 0, "fuse_concat": 0, "conv_patch96": 1, "conv_patch_tail": 2, "conv_tail_f32": 1, "conv_src_f32": 1}
 
 
 def load(suffix):
@@ -130,9 +130,10 @@ def main():
                 qkv = L.QkvEpilogue(q=Q.data_ptr(), k=K.data_ptr(), v=V.data_ptr(), heads=heads, nj=3, rows_per_b=1, koff=0, kl=S, qscale=0.18)
                 out = torch.cat([Q, K, V])                  # (a copy: the comparison below is then trivially 0; timing only)
             tailf = knobs.pop("tailf32", 0) if c1 else 0    # 1: the tail segment read from the fp32 tensor (vh_conv_args.tail_f32)
+            srcf = knobs.pop("srcf32", 0)                   # 1: the main loop reads the fp32 tensor through mp_silu (vh_conv_args.src_f32): no S8 input
             s8mode = knobs.pop("s8", 0)                     # 0: fp32 output, 1: S8 only, 2: both
             o8 = torch.empty(M * cout, device="cuda") if s8mode else None
-            a = L.ConvArgs(src0=s8.data_ptr(), src1=(x1.data_ptr() if tailf else s81.data_ptr()) if c1 else None, tail_f32=tailf, c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=knobs.pop("up", 0), taps=taps, pro=0,
+            a = L.ConvArgs(src0=x.data_ptr() if srcf else s8.data_ptr(), src_f32=srcf, src1=(x1.data_ptr() if tailf else s81.data_ptr()) if c1 else None, tail_f32=tailf, c0=cin, c1=c1, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=knobs.pop("up", 0), taps=taps, pro=1 if srcf == 1 else 0,
                            wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=scr.data_ptr(),
                            scratch_floats=scr.numel(), cout=cout, out=out.data_ptr() if (s8mode != 1 and epi != 3) else None, out_s8=o8.data_ptr() if o8 is not None else None,
                            out_s8_c=cout if o8 is not None else 0, prec=1, kernel=1, epi=epi,

@@ -49,7 +49,7 @@ class ConvArgs(C.Structure):
                 ("cvec", C.c_void_p), ("cvec_ld", C.c_int), ("res", C.c_void_p), ("res_up", C.c_int), ("res_scale", C.c_void_p),
                 ("ta", C.c_float), ("tb", C.c_float), ("clip", C.c_float), ("qkv", C.c_void_p), ("stagger", C.c_int),
                 ("korder", C.c_int), ("tile", C.c_int), ("sink", S8Sink * 2),
-                ("tail_f32", C.c_int), ("src2", C.c_void_p), ("c2", C.c_int), ("scale2", C.c_float)]
+                ("tail_f32", C.c_int), ("src2", C.c_void_p), ("c2", C.c_int), ("scale2", C.c_float), ("src_f32", C.c_int)]
 
 
 class PixnormArgs(C.Structure):

@@ -41,6 +41,7 @@ struct ConvK {
     unsigned long long* dbg;        // VH_CLOCK builds: [workgroup][2] = shader cycles, 100 MHz ticks of the K loop
     // conv_x3_patch: extra S8 outputs (vh_s8_sink) - the result scaled, optionally through mp_silu, into channels [off, off + cout) of rows of ct channels
     unsigned short* sk_ptr[2]; int sk_ct[2], sk_off[2]; float sk_scale[2]; int sk_silu[2];
+    int src_f32;                    // conv_x3_patch: src0 / src1 are fp32 NHWC sources of the MAIN loop (channel concat, scale0 / scale1, pro), vh_conv_args.src_f32
     const float* src2; int c2; float scale2; int tail_f32;   // conv_x3_patch: fp32 tail sources (vh_conv_args.tail_f32): src1 / src2 fp32 NHWC, c1 / c2 channels, scale1 / scale2
     int ptx, pty; FastDiv div_ptx, div_ptiles;   // conv_x3_patch: 16x16-pixel tiles per image row / column, n / ptx, n / (ptx*pty)
     int ksplit; float* scratch;     // split-K: this launch covers K-tiles [ks*KT/ksplit, (ks+1)*KT/ksplit) and

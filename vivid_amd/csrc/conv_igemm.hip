@@ -250,8 +250,12 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
                    "vh_conv: sink %d: c_total / c_off must be multiples of 32 with c_off + cout <= c_total (cout %% 32 == 0), 16-byte aligned", i);
     VH_REQUIRE(a.prec == VH_PREC_F32 || a.prec == VH_PREC_BF16X3, "vh_conv: bad prec %d", a.prec);
     // bf16x3 + VH_CONV_GLDS256 + 3x3: a second S8 source is a 1-TAP TAIL SEGMENT of the K loop (see vh_conv_args.src1), not a channel concat
-    const bool tail = a.prec == VH_PREC_BF16X3 && a.src1 != nullptr;
-    if (a.prec == VH_PREC_BF16X3) {
+    const bool tail = a.prec == VH_PREC_BF16X3 && a.src1 != nullptr && !a.src_f32;
+    if (a.src_f32) {
+        VH_REQUIRE(a.prec == VH_PREC_BF16X3 && a.kernel == VH_CONV_GLDS256 && a.taps == 9 && a.epi != VH_EPI_QKV && !a.tail_f32,
+                   "vh_conv: src_f32 belongs to a 3x3 VH_PREC_BF16X3 / VH_CONV_GLDS256 convolution without a tail segment");
+        VH_REQUIRE(a.c0 % 32 == 0 && a.c1 % 32 == 0 && a.cin_pad == a.c0 + a.c1, "vh_conv: src_f32 needs c0, c1 multiples of 32 and cin_pad == c0 + c1 (got %d, %d, %d)", a.c0, a.c1, a.cin_pad);
+    } else if (a.prec == VH_PREC_BF16X3) {
         VH_REQUIRE(a.pro == VH_PRO_NONE && a.scale0 == 1.0f, "vh_conv: bf16x3 takes pre-split (S8) sources; scale/silu/concat belong to their producer");
         VH_REQUIRE(a.c0 % 32 == 0 && a.cin_pad == a.c0, "vh_conv: bf16x3 needs c0 == cin_pad, a multiple of 32 (got %d, %d)", a.c0, a.cin_pad);
         VH_REQUIRE(!tail || (a.kernel == VH_CONV_GLDS256 && a.taps == 9 && !a.up && a.c1 > 0 && a.c1 % 32 == 0 && (a.scale1 == 1.0f || a.tail_f32) && a.epi != VH_EPI_QKV),
@@ -308,7 +312,7 @@ extern "C" int vh_conv(vh_ctx* ctx, const vh_conv_args* p) {
     k.div_hw = fastdiv_make((unsigned)(a.h * a.w)); k.div_w = fastdiv_make((unsigned)a.w); k.div_c0u = fastdiv_make((unsigned)(a.c0 / 4));
     k.ksplit = 1; k.scratch = nullptr; k.korder = 0; k.stagger = 0; k.dbg = nullptr;
     k.ptx = k.pty = 0; k.div_ptx = k.div_ptiles = fastdiv_make(1);
-    k.src2 = a.src2; k.c2 = a.c2; k.scale2 = a.scale2; k.tail_f32 = a.tail_f32 ? 1 : 0;
+    k.src2 = a.src2; k.c2 = a.c2; k.scale2 = a.scale2; k.tail_f32 = a.tail_f32 ? 1 : 0; k.src_f32 = a.src_f32 ? 1 : 0;
     for (int i = 0; i < 2; ++i) {
         k.sk_ptr[i] = static_cast<unsigned short*>(a.sink[i].ptr); k.sk_ct[i] = a.sink[i].c_total; k.sk_off[i] = a.sink[i].c_off;
         k.sk_scale[i] = a.sink[i].scale; k.sk_silu[i] = a.sink[i].silu;

@@ -175,8 +175,13 @@ __device__ __forceinline__ void bf16_split_pair_p(float a, float b, unsigned& H,
 // wave-private 4 KB LDS area (any NJ: each wave's 32 pixels are read by that wave alone, so their staging needs no barrier and no second stage);
 // 3 = 2 with fp32 sources (vh_conv_args.tail_f32): the registers the pieces pass through anyway are where mp_cat's scale and the bf16 hi / lo split
 // are applied, so no raw S8 form of the concat has to exist in memory.
-template <int NJ, int TAIL, bool PF>
+// RS ("register-staged sources", vh_conv_args.src_f32): the main loop's input is not an S8 tensor but the fp32 tensors a producer would have made it
+// from - one or two NHWC sources as a channel concat, each times its mp_cat weight, optionally through mp_silu (conv_res0 of a decoder block reads
+// mp_silu(mp_cat(x, skip)), training/models.py:78-84, :174).  At every chunk boundary the patch goes global -> registers -> (scale, mp_silu, bf16
+// hi / lo split: vh_split's operations and roundings) -> LDS instead of by LDS-DMA: the vh_split pass and its S8 tensor do not exist.
+template <int NJ, int TAIL, bool PF, bool RS = false>
 __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
+    static_assert(!RS || (TAIL == 0 && !PF && NJ >= 4), "register-staged sources: plain main loop only");
     static_assert(NJ == 1 || NJ == 4 || NJ == 6 || NJ == 8, "16 (narrow outputs: the 3-channel out_conv), 64, 96 or 128 output channels per workgroup");
     static_assert(!(NJ == 1 && TAIL != 0), "the narrow form has no tail segment");
     static_assert(TAIL >= 0 && TAIL <= 3, "tail modes 0-3");
@@ -256,6 +261,42 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
         if (w == 0) glds16p(piece_src(PR - 1, (unsigned)cu, tq), ldsP_w + (PR - 1) * 8192u);
     };
 
+    // RS: chunk c of the concat, global fp32 -> registers -> scale / mp_silu / split -> the patch image.  Slot j*512 + t = (patch pixel p, channel quad
+    // cq): 16 bytes = channels 4cq .. 4cq+3 of the chunk (8 lanes = the pixel's 128 bytes); hi pairs go to unit cq>>1, half cq&1, lo pairs to unit 4 + (cq>>1)
+    auto stage_f32 = [&](int c) __attribute__((always_inline)) {
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        const int n0c = a.c0 >> 5;
+        const bool first = c < n0c;
+        const float4* s4 = reinterpret_cast<const float4*>(first ? a.src0 : a.src1);
+        const unsigned cs4 = (unsigned)((first ? a.c0 : a.c1) >> 2), cu = (unsigned)(first ? c : c - n0c) * 8u;
+        const float sc = first ? a.scale0 : a.scale1;
+        uint2* const sP2 = reinterpret_cast<uint2*>(sP);
+        auto one = [&](int j, bool active) __attribute__((always_inline)) {
+            const int slot = j * 512 + (j == PR - 1 ? (tq & 63) : tq);
+            const int p = slot >> 3, cq = slot & 7;
+            const int py = (p * 3641) >> 16, px = p - py * PP;
+            const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+            const bool inside = active && p < PPIX && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+            const int sy = a.up ? (yy >> 1) : yy, sx = a.up ? (xx >> 1) : xx;
+            const f32x4 r = *reinterpret_cast<const f32x4*>(inside ? s4 + (size_t)((img_off + (unsigned)(sy * Ws + sx)) * cs4 + (unsigned)cq + cu) : zp);
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = mul_rounded(r[k], sc);
+                if (a.pro == VH_PRO_SILU) v[k] = mp_silu_dev(v[k]);
+            }
+            unsigned H0, L0, H1, L1;
+            bf16_split_pair_p(v[0], v[1], H0, L0);
+            bf16_split_pair_p(v[2], v[3], H1, L1);
+            const int ih = (p * 8 + ((cq >> 1) ^ (p & 7))) * 2 + (cq & 1);       // 8-byte half of hi unit cq>>1 (swizzled p & 7); its lo unit is 4 units on: ^ 8 in halves
+            if (active && p < PPIX + 4) { sP2[ih] = make_uint2(H0, H1); sP2[ih ^ 8] = make_uint2(L0, L1); }
+        };
+#pragma unroll
+        for (int j = 0; j < PR - 1; ++j) one(j, true);
+        if (w == 0) one(PR - 1, true);
+    };
+
     // ---- weight staging (as conv_x3_glds): row = output channel w*8 + (l>>3), LDS unit l&7, swizzle (row>>1)&7 on the source side
     const int KU = a.k_pad >> 2;
     const int uslotB = (l & 7) ^ (((w & 1) << 2) | (l >> 4));
@@ -319,8 +360,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 #ifdef VH_CLOCK
     PCK(ck_p1);
 #endif
-    load_patch(0);
-    issueB(0, 0);
+    if constexpr (RS) { issueB(0, 0); stage_f32(0); } else { load_patch(0); issueB(0, 0); }
     wait_dma_p();
     __syncthreads();
 #ifdef VH_CLOCK
@@ -348,6 +388,9 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 #pragma unroll
                 for (int j = PXL; j < PR - 1; ++j) *reinterpret_cast<f32x4*>(&sP[j * 512 + t]) = nx[j - PXL];
                 if (w == 0) sP[(PR - 1) * 512 + l] = sX[PXL * 512 + l];
+            } else if constexpr (RS) {
+                stage_f32(c);
+                wait_dma_p();
             } else {
                 load_patch(c * 8);
                 wait_dma_p();
@@ -654,13 +697,19 @@ void vh_conv_x3_patch_launch(vhconv::ConvK k, hipStream_t s) {
         else hipLaunchKernelGGL((conv_x3_patch<1, 0, false>), dim3(grid), dim3(512), 0, s, k);
         return;
     }
-    const int tmode = k.c1 > 0 ? (k.tail_f32 ? 3 : vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1 ? 1 : 2) : 0;
+    const int tmode = (k.c1 > 0 && !k.src_f32) ? (k.tail_f32 ? 3 : vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1 ? 1 : 2) : 0;
     const bool wide = k.cout > 64 && tmode != 1;
     const bool n96 = wide && k.cout % 96 == 0 && k.cout % 128 != 0;
     const int bn = n96 ? 96 : wide ? 128 : 64;
     k.NT = (k.cout + bn - 1) / bn;
     const unsigned grid = (unsigned)((long long)(k.M / k.HW) * k.ptx * k.pty * k.NT);
     const bool pf = k.cin_pad <= 64 && bn == 64;
+    if (k.src_f32) {                                         // register-staged fp32 sources (no tail, no look-ahead patch; validated by vh_conv)
+        if (n96) hipLaunchKernelGGL((conv_x3_patch<6, 0, false, true>), dim3(grid), dim3(512), 0, s, k);
+        else if (wide) hipLaunchKernelGGL((conv_x3_patch<8, 0, false, true>), dim3(grid), dim3(512), 0, s, k);
+        else hipLaunchKernelGGL((conv_x3_patch<4, 0, false, true>), dim3(grid), dim3(512), 0, s, k);
+        return;
+    }
 #define VH_PATCH_LAUNCH(NJ_, T_, PF_) hipLaunchKernelGGL((conv_x3_patch<NJ_, T_, PF_>), dim3(grid), dim3(512), 0, s, k)
     if (tmode == 0) {
         if (n96) VH_PATCH_LAUNCH(6, 0, false); else if (wide) VH_PATCH_LAUNCH(8, 0, false); else if (pf) VH_PATCH_LAUNCH(4, 0, true); else VH_PATCH_LAUNCH(4, 0, false);

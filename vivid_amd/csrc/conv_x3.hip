@@ -639,7 +639,8 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
                           (double)M * a.c0 / 4.0 < 4294967296.0 && (double)M * a.c1 / 4.0 < 4294967296.0 && (double)M * a.c2 / 4.0 < 4294967296.0;
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
     const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
-    const bool tailp = a.src1 != nullptr;
+    const bool tailp = a.src1 != nullptr && !a.src_f32;
+    if (a.src_f32 && (vh_knob(VH_KNOB_CONV_SRC_F32) == 0 || narrow)) return a.tile == VH_TILE_PATCH16 ? -1 : 0;
     const int tf = vh_knob(VH_KNOB_CONV_TAIL_F32);
     if (a.tail_f32 && (tf == 0 || vh_knob(VH_KNOB_CONV_PATCH_TAIL) == 1)) return a.tile == VH_TILE_PATCH16 ? -1 : 0;      // (fp32 tails exist in the wave-private form only)
     const bool wide_ok = !tailp || vh_knob(VH_KNOB_CONV_PATCH_TAIL) != 1;                                           // (the staged tail exists for 64-channel blocks only)
@@ -671,6 +672,8 @@ int vh_conv_x3_glds_dispatch(vh_ctx* ctx, const vh_conv_args& a, ConvK k, double
         if (pc < 0) return vh_fail(VH_EINVAL, "vh_conv: VH_TILE_PATCH16 needs a 3x3 convolution with cout %% 32 == 0 or a plain fp32 store of cout <= 16 (got taps %d, cout %d)", a.taps, a.cout);
         if ((a.sink[0].ptr || a.sink[1].ptr) && pc != 1)
             return vh_fail(VH_EINVAL, "vh_conv: S8 sinks given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
+        if (a.src_f32 && pc != 1)
+            return vh_fail(VH_EINVAL, "vh_conv: src_f32 given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
         if (a.tail_f32 && pc != 1)
             return vh_fail(VH_EINVAL, "vh_conv: tail_f32 given, but these arguments do not take the patch-resident kernel (ask vh_conv_takes_patch first)");
         if (pc == 1) {

@@ -217,6 +217,7 @@ struct ConvOpt {
     int up = 0, epi = VH_EPI_STORE; const float* cvec = nullptr; int cvec_ld = 0; const Buf* res = nullptr; int res_up = 0;
     float ta = 0.f, tb = 0.f, clip = 0.f; Buf* out = nullptr; bool s8_only = false, also_s8 = false; const vh_qkv_epilogue* qkv = nullptr;
     const Buf* src1 = nullptr;        // S8 second source: the 1-tap tail segment of a fused conv_res1 + conv_skip
+    bool src_f32 = false; const Buf* f1 = nullptr; float fsc0 = 1.f, fsc1 = 1.f; int pro = VH_PRO_NONE;   // `src` (and f1) are the fp32 tensors of the input concat (vh_conv_args.src_f32)
     const Buf* tail0 = nullptr; const Buf* tail1 = nullptr; float tsc0 = 1.f, tsc1 = 0.f;     // ... or the fp32 tensors x, skip themselves with their mp_cat weights (vh_conv_args.tail_f32)
     const Buf* res_scale = nullptr;   // per-pixel factor of the residual
     int sink_j = -1, sink_half = 0;   // this result is half 0 (x) / 1 (skip) of decoder block sink_j's concat input: written as S8 by this launch if it takes the patch kernel
@@ -251,11 +252,15 @@ std::pair<Buf, Buf> conv(vh_net* n, const Buf& src, const Weight& W, int rows, i
     if (!o.s8_only && !o.qkv && !skip_fp32) { if (o.out) out = *o.out; else out = alloc(n, rows, h, w, W.cout); }
     vh_conv_args a{};
     a.src0 = ptr(n, src); a.src1 = o.src1 ? ptr(n, *o.src1) : nullptr; a.c0 = src.c; a.c1 = o.src1 ? o.src1->c : 0; a.scale0 = 1.f; a.scale1 = 1.f;
+    if (o.src_f32) {
+        a.src_f32 = 1; a.scale0 = o.fsc0;
+        if (o.f1) { a.src1 = ptr(n, *o.f1); a.c1 = o.f1->c; a.scale1 = o.fsc1; }
+    }
     if (o.tail0) {
         a.tail_f32 = 1; a.src1 = ptr(n, *o.tail0); a.c1 = o.tail0->c; a.scale1 = o.tsc0;
         if (o.tail1) { a.src2 = ptr(n, *o.tail1); a.c2 = o.tail1->c; a.scale2 = o.tsc1; }
     }
-    a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = VH_PRO_NONE;
+    a.rows = rows; a.h = h; a.w = w; a.up = o.up; a.taps = W.taps; a.pro = o.src_f32 ? o.pro : VH_PRO_NONE;
     a.wt = W.wt; a.cin_pad = W.cin_pad; a.k_pad = W.k_pad; a.zeros = n->zeros; a.zeros_bytes = ZEROS_FLOATS * 4; a.cout = W.cout;
     a.scratch = n->scratch; a.scratch_floats = SCRATCH_FLOATS;
     a.out = ptr(n, out); a.out_s8 = ptr(n, out8); a.out_s8_c = out8.ok() ? W.cout : 0;
@@ -365,7 +370,7 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
         const long long npix_in = up ? npix / 4 : npix;
         const int Rin = up ? R / 2 : R;
         std::pair<Buf, Buf> cs;
-        bool tail32 = false;
+        bool tail32 = false, src32 = false;
         CatState* st = (cat_j >= 0 && skip) ? &n->cat.at(cat_j) : nullptr;
         if (st && (st->x_done || st->skip_done)) {
             // at least one half of mp_silu(mp_cat(x, skip)) was written by its producer (vh_s8_sink); vh_split fills in the other, if any
@@ -382,11 +387,30 @@ std::pair<Buf, Buf> block(vh_net* n, const std::string& prefix, const Block& b, 
                 q.rows = rows; q.h = R; q.w = R; q.up = 0; q.taps = 9; q.cout = C; q.prec = VH_PREC_BF16X3; q.kernel = VH_CONV_GLDS256; q.epi = VH_EPI_STORE;
                 tail32 = vh_conv_takes_patch(&q) == 1;
             }
-            cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, has_skip_conv && !tail32);
+            // ... and conv_res0 stages its patches from the fp32 tensors itself (vh_conv_args.src_f32; engine.Engine._src_f32): then no vh_split pass at all
+            if (x.c % 32 == 0 && (!skip || skip->c % 32 == 0)) {
+                vh_conv_args q{};
+                q.src0 = reinterpret_cast<const float*>(16); q.src1 = skip ? reinterpret_cast<const float*>(16) : nullptr; q.out_s8 = reinterpret_cast<void*>(16);
+                q.c0 = x.c; q.c1 = skip ? skip->c : 0; q.src_f32 = 1; q.pro = VH_PRO_SILU;
+                q.rows = rows; q.h = R; q.w = R; q.up = up; q.taps = 9; q.cout = C; q.prec = VH_PREC_BF16X3; q.kernel = VH_CONV_GLDS256; q.epi = VH_EPI_SCALE_SILU;
+                src32 = vh_conv_takes_patch(&q) == 1;
+            }
+            if (has_skip_conv && !tail32) {
+                if (src32) cs.second = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_NONE, false).first;
+                else cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, true);
+            } else if (!src32) {
+                cs = split(n, x, sc0, skip, sc1, npix_in, rows, Rin, Rin, VH_PRO_SILU, false);
+            }
         }
         ConvOpt o0; o0.up = up; o0.epi = VH_EPI_SCALE_SILU; o0.cvec = cv; o0.cvec_ld = emb.total; o0.s8_only = true;
-        Buf y = conv(n, cs.first, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
-        release(n, cs.first);
+        Buf y;
+        if (src32) {
+            o0.src_f32 = true; o0.f1 = skip; o0.fsc0 = sc0; o0.fsc1 = sc1; o0.pro = VH_PRO_SILU;
+            y = conv(n, x, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
+        } else {
+            y = conv(n, cs.first, n->W.at(p + "conv_res0.weight"), rows, R, R, o0).second;
+            release(n, cs.first);
+        }
         std::pair<Buf, Buf> r;
         if (has_skip_conv) {
             // conv_res1 + conv_skip as one GEMM: the raw concat is the 1-tap tail segment, ta / tb are folded into the weights

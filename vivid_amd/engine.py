@@ -260,6 +260,15 @@ class Engine:
                        tail_f32=1, rows=rows, h=b.res, w=b.res, up=0, taps=9, cout=b.cout, prec=1, kernel=1, epi=L_EPI_STORE, out=16)
         return L.lib().vh_conv_takes_patch(C.byref(q)) == 1
 
+    def _src_f32(self, b: BlockSpec, rows: int, srcs, up: int) -> bool:
+        """Does conv_res0 of decoder block b stage its patches from the fp32 tensors themselves (vh_conv_args.src_f32: mp_cat weights, mp_silu and the
+        bf16 split applied in the kernel - no vh_split pass)?  The library answers (vh_conv_takes_patch)."""
+        if not (self.x3 and self.glds and self.hook is None and all(s_.shape[-1] % 32 == 0 for s_, _ in srcs)):
+            return False
+        q = L.ConvArgs(src0=16, src1=16 if len(srcs) > 1 else None, c0=srcs[0][0].shape[-1], c1=srcs[1][0].shape[-1] if len(srcs) > 1 else 0, src_f32=1,
+                       rows=rows, h=b.res, w=b.res, up=up, taps=9, pro=L_PRO_SILU, cout=b.cout, prec=1, kernel=1, epi=L_EPI_SCALE_SILU, out_s8=16)
+        return L.lib().vh_conv_takes_patch(C.byref(q)) == 1
+
     def _prep_fused_res1_skip(self, p: str, b: BlockSpec):
         ta, tb = self._mp_sum_coeffs(self.cfg.res_balance)
         w1, ws = self._params[p + "conv_res1.weight"], self._params[p + "conv_skip.weight"]
@@ -352,9 +361,11 @@ class Engine:
     def _conv(self, srcs: Sequence[Tuple[Buf, float]], W: Weight, rows, h, w, *, up=0, pro=0, epi=0,
               cvec: Optional[Tuple[int, int]] = None, res: Optional[Buf] = None, res_up=0, res_scale: Optional[Buf] = None,
               ta=0.0, tb=0.0, clip=0.0, out: Optional[Buf] = None, prec=0, s8_only=False, also_s8=False, qkv=None,
-              sink_plan: Optional[Tuple[int, str]] = None, fp32_optional=False, tail_f32=False):
+              sink_plan: Optional[Tuple[int, str]] = None, fp32_optional=False, tail_f32=False, src_f32=False):
         """prec=1: srcs[0] is an S8 (bf16 hi/lo) buffer.  tail_f32: srcs[1:] are the fp32 tensors of the 1-tap tail segment with their mp_cat weights
-        (vh_conv_args.tail_f32: the bf16 split happens while the tail is staged; no raw S8 concat exists).  s8_only: the result is written only as S8;
+        (vh_conv_args.tail_f32: the bf16 split happens while the tail is staged; no raw S8 concat exists).  src_f32 (with prec=1): srcs are the 1-2
+        fp32 tensors of the input concat with their mp_cat weights and `pro` applies, as in fp32 mode - the patch-resident kernel splits them while
+        it stages its patches (vh_conv_args.src_f32).  s8_only: the result is written only as S8;
         also_s8: fp32 and S8 copies are both written and (out, out_s8) is returned.
         qkv (L.QkvEpilogue): the result goes straight into attention operand buffers (VH_EPI_QKV); nothing is returned."""
         out_s8 = None
@@ -364,6 +375,7 @@ class Engine:
         s1, sc1 = srcs[1] if len(srcs) > 1 else (None, 1.0)
         s2, sc2 = srcs[2] if len(srcs) > 2 else (None, 0.0)
         assert s2 is None or tail_f32
+        assert not (src_f32 and tail_f32)
         # sink_plan = (dec block index, "x" | "skip"): this result is one half of that block's concat input.  If the launch takes the patch-resident
         # kernel (the library's own rule: vh_conv_takes_patch), it writes the S8 forms itself (fp32_optional: and nothing else reads the fp32 form)
         sinks = None
@@ -392,11 +404,12 @@ class Engine:
                        ta=ta, tb=tb, clip=clip,
                        qkv=C.addressof(qkv) if qkv is not None else None,
                        stagger=self.conv_stagger if (prec and self.glds) else 0,
-                       tail_f32=int(tail_f32), src2=s2.ptr if s2 is not None else None, c2=s2.shape[-1] if s2 is not None else 0, scale2=sc2)
+                       tail_f32=int(tail_f32), src2=s2.ptr if s2 is not None else None, c2=s2.shape[-1] if s2 is not None else 0, scale2=sc2,
+                       src_f32=int(src_f32))
         for i, (buf, ct, off, scale, silu) in enumerate(sinks or []):
             a.sink[i] = L.S8Sink(ptr=buf.ptr, c_total=ct, c_off=off, scale=scale, silu=silu)
         self._call("vh_conv", a, f"{W.taps}tap rows={rows} {h}x{w} cin={a.c0 + a.c1 + a.c2} cout={W.cout} up={up} pro={pro} epi={epi} prec={prec}"
-                   + (f" sinks={len(sinks)}" if sinks else "") + (" tail=fp32" if tail_f32 else ""))
+                   + (f" sinks={len(sinks)}" if sinks else "") + (" tail=fp32" if tail_f32 else "") + (" src=fp32" if src_f32 else ""))
         if skip_fp32:
             return Ghost((rows, h, w, W.cout))
         if qkv is not None:
@@ -574,7 +587,7 @@ class Engine:
                 srcs = [(x, Cc / math.sqrt(Na) * (1 - t)), (skip, Cc / math.sqrt(Nb) * t)]
             else:
                 srcs = [(x, 1.0)]
-            craw, tail32 = None, False
+            craw, tail32, src32 = None, False, False
             st = self._cat.get(cat_j) if (cat_j is not None and skip is not None) else None
             if x3 and st is not None and (st["x_done"] or st["skip_done"]):
                 # at least one half of mp_silu(mp_cat(x, skip)) was written by its producer (vh_s8_sink); vh_split fills in the other, if any
@@ -585,12 +598,21 @@ class Engine:
                 cs, craw = st["cs"], st["craw"]
             elif x3:
                 # mp_silu(mp_cat(...)) once per element as S8; the raw split is conv_skip's input - unless the fused launch reads x and skip as fp32
+                # (tail_f32), and conv_res0 stages its patches from the fp32 tensors itself (src_f32): then no vh_split pass at all
                 tail32 = has_skip_conv and not up and self._tail_f32(b, rows, srcs)
+                src32 = self._src_f32(b, rows, srcs, up)
+                cs = None
                 if has_skip_conv and not tail32:
-                    cs, craw = self._split(srcs, L_PRO_SILU, raw_too=True)
-                else:
+                    if src32:
+                        craw = self._split(srcs, 0)
+                    else:
+                        cs, craw = self._split(srcs, L_PRO_SILU, raw_too=True)
+                elif not src32:
                     cs = self._split(srcs, L_PRO_SILU)
-            if x3:
+            if x3 and src32:
+                y = self._conv(srcs, self.W[p + "conv_res0.weight"], rows, R, R, up=up, pro=L_PRO_SILU,
+                               epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True, src_f32=True)
+            elif x3:
                 y = self._conv([(cs, 1.0)], self.W[p + "conv_res0.weight"], rows, R, R, up=up,
                                epi=L_EPI_SCALE_SILU, cvec=cv, prec=1, s8_only=True)
                 self._free(cs)
