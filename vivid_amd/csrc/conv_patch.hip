@@ -263,7 +263,61 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 
     // RS: chunk c of the concat, global fp32 -> registers -> scale / mp_silu / split -> the patch image.  Slot j*512 + t = (patch pixel p, channel quad
     // cq): 16 bytes = channels 4cq .. 4cq+3 of the chunk (8 lanes = the pixel's 128 bytes); hi pairs go to unit cq>>1, half cq&1, lo pairs to unit 4 + (cq>>1)
+    // Two halves: fetch (global -> registers; with RSP two K-tiles ahead of the boundary, so the latency runs under taps 7 and 8) and convert (-> LDS).
+    constexpr bool RSP = RS && NJ < 8;                         // look-ahead fetch where the K loop has 24 registers to spare (64 / 96-channel blocks)
+    f32x4 rr[RSP ? PR : 1];
+    (void)rr;
+    auto rs_coords = [&](int j, int tq, int& p, int& cq) __attribute__((always_inline)) {
+        const int slot = j * 512 + (j == PR - 1 ? (tq & 63) : tq);
+        p = slot >> 3; cq = slot & 7;
+    };
+    auto fetch_f32 = [&](int c) __attribute__((always_inline)) {
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        const int n0c = a.c0 >> 5;
+        const bool first = c < n0c;
+        const float4* s4 = reinterpret_cast<const float4*>(first ? a.src0 : a.src1);
+        const unsigned cs4 = (unsigned)((first ? a.c0 : a.c1) >> 2), cu = (unsigned)(first ? c : c - n0c) * 8u;
+        auto one = [&](int j) __attribute__((always_inline)) {
+            int p, cq;
+            rs_coords(j, tq, p, cq);
+            const int py = (p * 3641) >> 16, px = p - py * PP;
+            const int yy = y0 - 1 + py, xx = x0 - 1 + px;
+            const bool inside = p < PPIX && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+            const int sy = a.up ? (yy >> 1) : yy, sx = a.up ? (xx >> 1) : xx;
+            rr[j] = *reinterpret_cast<const f32x4*>(inside ? s4 + (size_t)((img_off + (unsigned)(sy * Ws + sx)) * cs4 + (unsigned)cq + cu) : zp);
+        };
+#pragma unroll
+        for (int j = 0; j < PR - 1; ++j) one(j);
+        if (w == 0) one(PR - 1);
+    };
+    auto convert_f32 = [&](int c) __attribute__((always_inline)) {
+        int tq = t;
+        asm volatile("" : "+v"(tq));
+        const float sc = c < (a.c0 >> 5) ? a.scale0 : a.scale1;
+        uint2* const sP2 = reinterpret_cast<uint2*>(sP);
+        auto one = [&](int j) __attribute__((always_inline)) {
+            int p, cq;
+            rs_coords(j, tq, p, cq);
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k] = mul_rounded(rr[j][k], sc);
+                if (a.pro == VH_PRO_SILU) v[k] = mp_silu_dev(v[k]);
+            }
+            unsigned H0, L0, H1, L1;
+            bf16_split_pair_p(v[0], v[1], H0, L0);
+            bf16_split_pair_p(v[2], v[3], H1, L1);
+            const int ih = (p * 8 + ((cq >> 1) ^ (p & 7))) * 2 + (cq & 1);       // 8-byte half of hi unit cq>>1 (swizzled p & 7); its lo unit is 4 units on: ^ 8 in halves
+            if (p < PPIX + 4) { sP2[ih] = make_uint2(H0, H1); sP2[ih ^ 8] = make_uint2(L0, L1); }
+        };
+#pragma unroll
+        for (int j = 0; j < PR - 1; ++j) one(j);
+        if (w == 0) one(PR - 1);
+    };
+    // without look-ahead (128-channel blocks: no registers to carry the pieces): piece by piece, each through four registers of its own
     auto stage_f32 = [&](int c) __attribute__((always_inline)) {
+        if constexpr (RSP) { fetch_f32(c); convert_f32(c); return; }
         int tq = t;
         asm volatile("" : "+v"(tq));
         const int n0c = a.c0 >> 5;
@@ -272,12 +326,12 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
         const unsigned cs4 = (unsigned)((first ? a.c0 : a.c1) >> 2), cu = (unsigned)(first ? c : c - n0c) * 8u;
         const float sc = first ? a.scale0 : a.scale1;
         uint2* const sP2 = reinterpret_cast<uint2*>(sP);
-        auto one = [&](int j, bool active) __attribute__((always_inline)) {
-            const int slot = j * 512 + (j == PR - 1 ? (tq & 63) : tq);
-            const int p = slot >> 3, cq = slot & 7;
+        auto one = [&](int j) __attribute__((always_inline)) {
+            int p, cq;
+            rs_coords(j, tq, p, cq);
             const int py = (p * 3641) >> 16, px = p - py * PP;
             const int yy = y0 - 1 + py, xx = x0 - 1 + px;
-            const bool inside = active && p < PPIX && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
+            const bool inside = p < PPIX && (unsigned)yy < (unsigned)a.h && (unsigned)xx < (unsigned)a.w;
             const int sy = a.up ? (yy >> 1) : yy, sx = a.up ? (xx >> 1) : xx;
             const f32x4 r = *reinterpret_cast<const f32x4*>(inside ? s4 + (size_t)((img_off + (unsigned)(sy * Ws + sx)) * cs4 + (unsigned)cq + cu) : zp);
             float v[4];
@@ -289,12 +343,12 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
             unsigned H0, L0, H1, L1;
             bf16_split_pair_p(v[0], v[1], H0, L0);
             bf16_split_pair_p(v[2], v[3], H1, L1);
-            const int ih = (p * 8 + ((cq >> 1) ^ (p & 7))) * 2 + (cq & 1);       // 8-byte half of hi unit cq>>1 (swizzled p & 7); its lo unit is 4 units on: ^ 8 in halves
-            if (active && p < PPIX + 4) { sP2[ih] = make_uint2(H0, H1); sP2[ih ^ 8] = make_uint2(L0, L1); }
+            const int ih = (p * 8 + ((cq >> 1) ^ (p & 7))) * 2 + (cq & 1);
+            if (p < PPIX + 4) { sP2[ih] = make_uint2(H0, H1); sP2[ih ^ 8] = make_uint2(L0, L1); }
         };
 #pragma unroll
-        for (int j = 0; j < PR - 1; ++j) one(j, true);
-        if (w == 0) one(PR - 1, true);
+        for (int j = 0; j < PR - 1; ++j) one(j);
+        if (w == 0) one(PR - 1);
     };
 
     // ---- weight staging (as conv_x3_glds): row = output channel w*8 + (l>>3), LDS unit l&7, swizzle (row>>1)&7 on the source side
@@ -388,6 +442,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
 #pragma unroll
                 for (int j = PXL; j < PR - 1; ++j) *reinterpret_cast<f32x4*>(&sP[j * 512 + t]) = nx[j - PXL];
                 if (w == 0) sP[(PR - 1) * 512 + l] = sX[PXL * 512 + l];
+            } else if constexpr (RSP) {
+                convert_f32(c);                                // (fetched during taps 7 and 8 of the chunk before)
             } else if constexpr (RS) {
                 stage_f32(c);
                 wait_dma_p();
@@ -408,6 +464,8 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
             if (tap < 8) issueB(st ^ 1, ((tap + 1) * a.cin_pad + c * 32) >> 2);
             else if (c + 1 < nch) issueB(st ^ 1, ((c + 1) * 32) >> 2);
             else if (TAIL != 0 && ntail > 0) issueB(st ^ 1, (9 * a.cin_pad) >> 2);
+            const bool rsp = RSP && tap == 7 && c + 1 < nch;
+            if (rsp) fetch_f32(c + 1);                         // plain loads behind this K-tile's weight DMA (in-order queue): the tile waits for all but these
             const bool pf = PF && tap == 0 && c + 1 < nch;
             if (pf) {
                 // plain loads, behind this K-tile's weight DMA in the wave's (in-order) memory queue: the tile waits for all but these
@@ -425,6 +483,7 @@ __global__ __launch_bounds__(512, 4) void conv_x3_patch(const ConvK a) {
             PCK(ck_k0);
 #endif
             if (pf) wait_dma_but<PR - 1 - PXL>();              // (the register-staged loads are the youngest; the LDS-DMA pieces before them are waited for with the weights)
+            else if (rsp) { if (w == 0) wait_dma_but<PR>(); else wait_dma_but<PR - 1>(); }
             else wait_dma_p();
             __syncthreads();
 #ifdef VH_CLOCK
