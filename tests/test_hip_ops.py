@@ -500,6 +500,63 @@ def test_conv_fp32_sources_equal_split_then_conv(ctx, cout, na, nb, h, w, up, pr
         ctx.call("vh_conv", a)
 
 
+def test_conv_patch_fp32_paths_random_shapes(ctx):
+    """Seeded random sweep of the patch-resident kernel's register-staged inputs (src_f32, tail_f32) against vh_split + the S8 launch - EQUAL bits:
+    image sizes that are not multiples of the 16-pixel tile (down to one partial tile), 1-3 rows, every block width, one / two sources of 32..256
+    channels, `up`, the three epilogues."""
+    import random
+    from vivid_amd import _lib as L
+    rnd = random.Random(1234)
+    for it in range(28):
+        cout = rnd.choice([64, 64, 128, 192, 256, 384])
+        na, nb = rnd.choice([32, 64, 96, 128, 256]), rnd.choice([0, 32, 64, 128])
+        rows, h, w = rnd.randint(1, 3), 2 * rnd.randint(4, 28), 2 * rnd.randint(4, 28)
+        tail = rnd.random() < 0.5
+        up = 0 if tail else rnd.choice([0, 0, 1])
+        epi = 0 if tail else rnd.choice([0, 1, 2])
+        g = torch.Generator().manual_seed(it)
+        hs, ws = (h // 2, w // 2) if up else (h, w)
+        Ms, M = rows * hs * ws, rows * h * w
+        xa = torch.randn(Ms, na, generator=g).cuda()
+        xb = torch.randn(Ms, nb, generator=g).cuda() if nb else None
+        sa, sb = 0.5 + rnd.random(), 0.5 + rnd.random()
+        cat = na + nb
+        cv = (torch.randn(rows, cout, generator=g) * 0.3 + 1).cuda()
+        res = torch.randn(M, cout, generator=g).cuda()
+        o1, o2 = torch.empty(M, cout, device="cuda"), torch.full((M, cout), float("nan"), device="cuda")
+        ekw = dict(epi=epi, cvec=cv.data_ptr() if epi == 1 else None, cvec_ld=cout if epi == 1 else 0, res=res.data_ptr() if epi == 2 else None, ta=0.6, tb=0.8,
+                   clip=3.0 if epi == 2 else 0.0)
+        if tail:        # y (S8, cout channels) x 3x3 weights + [xa | xb] x 1x1 weights
+            cin = cout
+            y = torch.randn(M, cin, generator=g).cuda()
+            ys8, craw = torch.empty(M * cin, device="cuda"), torch.empty(M * cat, device="cuda")
+            ctx.call("vh_split", L.SplitArgs(src0=y.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, pro=0, npix=M, c_pad=cin, out=ys8.data_ptr(), out_raw=None))
+            ctx.call("vh_split", L.SplitArgs(src0=xa.data_ptr(), src1=xb.data_ptr() if nb else None, c0=na, c1=nb, scale0=sa, scale1=sb, pro=0, npix=M, c_pad=cat,
+                                             out=craw.data_ptr(), out_raw=None))
+            k_pad = 9 * cin + cat
+            wt = (torch.randn(k_pad // 4 * cout * 4, generator=g) * 0.05).cuda().view(torch.int32).bitwise_and(-65536).view(torch.float32)
+            common = dict(src0=ys8.data_ptr(), c0=cin, scale0=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0, wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=_zeros(),
+                          zeros_bytes=65536, scratch=None, scratch_floats=0, cout=cout, out_s8=None, out_s8_c=0, prec=1, kernel=1, tile=8, **ekw)
+            ctx.call("vh_conv", L.ConvArgs(src1=craw.data_ptr(), c1=cat, scale1=1.0, out=o1.data_ptr(), **common))
+            ctx.call("vh_conv", L.ConvArgs(src1=xa.data_ptr(), c1=na, scale1=sa, src2=xb.data_ptr() if nb else None, c2=nb, scale2=sb if nb else 0.0, tail_f32=1,
+                                           out=o2.data_ptr(), **common))
+        else:
+            pro = rnd.choice([0, 1])
+            xs8 = torch.empty(Ms * cat, device="cuda")
+            ctx.call("vh_split", L.SplitArgs(src0=xa.data_ptr(), src1=xb.data_ptr() if nb else None, c0=na, c1=nb, scale0=sa, scale1=sb, pro=pro, npix=Ms, c_pad=cat,
+                                             out=xs8.data_ptr(), out_raw=None))
+            k_pad = 9 * cat
+            wt = (torch.randn(k_pad // 4 * cout * 4, generator=g) * 0.05).cuda().view(torch.int32).bitwise_and(-65536).view(torch.float32)
+            common = dict(rows=rows, h=h, w=w, up=up, taps=9, wt=wt.data_ptr(), cin_pad=cat, k_pad=k_pad, zeros=_zeros(), zeros_bytes=65536, scratch=None, scratch_floats=0,
+                          cout=cout, out_s8=None, out_s8_c=0, prec=1, kernel=1, tile=8, **ekw)
+            ctx.call("vh_conv", L.ConvArgs(src0=xs8.data_ptr(), src1=None, c0=cat, c1=0, scale0=1.0, scale1=1.0, pro=0, out=o1.data_ptr(), **common))
+            ctx.call("vh_conv", L.ConvArgs(src0=xa.data_ptr(), src1=xb.data_ptr() if nb else None, c0=na, c1=nb, scale0=sa, scale1=sb if nb else 1.0, pro=pro, src_f32=1,
+                                           out=o2.data_ptr(), **common))
+        torch.cuda.synchronize()
+        assert torch.isfinite(o1).all(), it
+        assert torch.equal(o1, o2), (it, cout, na, nb, rows, h, w, tail, up, epi)
+
+
 def test_conv_tail_segment_is_validated(ctx):
     from vivid_amd import _lib as L
     base = dict(src0=_zeros(), src1=_zeros(), c0=32, c1=32, scale0=1.0, scale1=1.0, rows=1, h=8, w=8, pro=0, wt=_zeros(), cin_pad=32,
