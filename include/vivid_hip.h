@@ -65,8 +65,8 @@ int vh_ctx_set_stream(vh_ctx* ctx, void* stream);
  * "conv_patch_tail": tail segment of the patch-resident kernel - 2 (default) staged per wave through registers, 1 through two LDS-DMA stages (A/B);
  * "conv_tail_f32": vh_conv_args.tail_f32 launches (and the whole-network walks, which ask vh_conv_takes_patch per decoder block) - 1 (default) wherever the
  *   patch-resident kernel takes a tail segment plus Cout = 256 from 64x64 up, 0 never (the walks fall back to vh_split's raw S8 form), 2 also Cout = 512 (A/B);
- * "conv_src_f32": vh_conv_args.src_f32 launches (and the walks' conv_res0 of decoder blocks, which ask vh_conv_takes_patch) - 1 (default) Cout = 64 and
- *   96-channel blocks (Cout = 192) under the patch-resident kernel's size rule, 2 every block width, 0 never (a vh_split pass and the S8 convolution instead);
+ * "conv_src_f32": vh_conv_args.src_f32 launches (and the walks' conv_res0 of decoder blocks, which ask vh_conv_takes_patch) - 2 (default) every block width
+ *   under the patch-resident kernel's size rule, 1 only Cout = 64 and 96-channel blocks (Cout = 192), 0 never (a vh_split pass and the S8 convolution instead);
  * "conv_patch_delay": start delay, in units of 2048 shader cycles, of every CU's second workgroup in the first round of a patch-kernel launch.
  * The library reads no environment variables.  Returns VH_EINVAL for an unknown name. */
 int vh_set_knob(const char* name, int value);

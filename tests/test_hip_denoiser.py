@@ -324,7 +324,7 @@ def test_fp32_tail_and_fp32_sources_change_nothing():
     from the fp32 tensors and split it while staging their tail; conv_res0 stages its patches from the same fp32 tensors (mp_cat weights, mp_silu,
     split in the kernel) - with both, a decoder block has no vh_split pass at all.  The staged bits are the bits vh_split wrote: the reference's SR
     stage at full size (the smallest preset whose launches take the patch kernel) must give EQUAL outputs in every combination of the two knobs
-    (src_f32: 1 = the 64- / 96-channel blocks, the default; 2 = every block width), in both walks."""
+    (src_f32: 1 = the 64- / 96-channel blocks only; 2 = every block width, the default), in both walks."""
     import vivid_amd
     from vivid_amd import _lib
     from vivid_amd.cnet import CNet
@@ -336,7 +336,7 @@ def test_fp32_tail_and_fp32_sources_change_nothing():
     sd = vivid_amd.synth_state_dict(cfg, seed=seed)
     outs, counts = [], []
     try:
-        for tail, srcf in ((1, 1), (0, 0), (2, 2), (1, 0), (0, 1)):
+        for tail, srcf in ((1, 1), (0, 0), (2, 2), (1, 0), (0, 1), (1, 2)):
             _lib.set_knob("conv_tail_f32", tail)
             _lib.set_knob("conv_src_f32", srcf)
             net = vivid_amd.NVPrecond.from_config(cfg, precision="bf16x3")
@@ -354,7 +354,7 @@ def test_fp32_tail_and_fp32_sources_change_nothing():
             counts.append((sum("tail=fp32" in d for d in log), sum("src=fp32" in d for d in log), sum(d.startswith("split") for d in log)))
     finally:
         _lib.set_knob("conv_tail_f32", 1)
-        _lib.set_knob("conv_src_f32", 1)
+        _lib.set_knob("conv_src_f32", 2)
     assert counts[1][0] == 0 and counts[1][1] == 0 and counts[0][0] > 0 and counts[0][1] > 0 and counts[2][0] >= counts[0][0] and counts[2][1] > counts[0][1], counts
     assert counts[0][2] < counts[3][2] <= counts[1][2] and counts[0][2] < counts[4][2] <= counts[1][2], counts       # fewer vh_split launches with either, fewest with both
     for o in outs[1:]:

@@ -22,7 +22,7 @@ import torch  # noqa: E402
 from vivid_amd import _lib as L  # noqa: E402
 
 
-KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0, "conv_patch": -1, "conv_patch_delay": 0, "fuse_concat": 0, "conv_patch96": 1, "conv_patch_tail": 2, "conv_tail_f32": 1, "conv_src_f32": 1}
+KNOB_DEFAULTS = {"attn_xcd": 1, "attn_m16": 1, "conv_korder": -1, "conv_stagger": -1, "attn_pipe": 1, "attn_nomax": 1, "conv_slim2": -1, "conv_korder_mb": 60, "conv_ksplit": 0, "conv_patch": -1, "conv_patch_delay": 0, "fuse_concat": 0, "conv_patch96": 1, "conv_patch_tail": 2, "conv_tail_f32": 1, "conv_src_f32": 2}
 
 
 def load(suffix):

@@ -37,7 +37,8 @@ if kind == "conv":
     ctx.call("vh_prep_weight", L.PrepWeightArgs(w=wgt.data_ptr(), cout=cout, cin=cin, taps=9, cin_pad=cin, k_pad=k_pad, gain_ptr=None, gain_value=1.0,
                                                 wt=wt.data_ptr(), dst_col0=0, dst_cols=cout, split=2))
     out = torch.empty(M, cout, device="cuda")
-    op, a = "vh_conv", L.ConvArgs(src0=s8.data_ptr(), src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=0,
+    srcf = int(os.environ.get("SRCF32", "0"))              # 1: vh_conv_args.src_f32 - the patch staged from the fp32 tensor through registers (mp_silu + split in the kernel)
+    op, a = "vh_conv", L.ConvArgs(src0=x.data_ptr() if srcf else s8.data_ptr(), src_f32=srcf, src1=None, c0=cin, c1=0, scale0=1.0, scale1=1.0, rows=rows, h=h, w=w, up=0, taps=9, pro=srcf,
                                   wt=wt.data_ptr(), cin_pad=cin, k_pad=k_pad, zeros=zeros.data_ptr(), zeros_bytes=65536, scratch=None, scratch_floats=0,
                                   cout=cout, out=out.data_ptr(), out_s8=None, out_s8_c=0, prec=1, kernel=1, epi=0, tile=int(os.environ.get('TILE', '0')))
     flops = 2.0 * M * cout * cin * 9

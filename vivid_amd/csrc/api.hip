@@ -6,7 +6,7 @@ std::string& vh_err() {
     return e;
 }
 
-static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0, 1, -1, -1, 1, 1, -1, 60, 0, -1, 0, 0, 1, 2, 1, 1};
+static int g_knobs[VH_NUM_KNOBS] = {1, 0, 0, 1, -1, -1, 1, 1, -1, 60, 0, -1, 0, 0, 1, 2, 1, 2};
 static const char* const g_knob_names[VH_NUM_KNOBS] = {"attn_xcd", "dbg_lo", "dbg_hi", "attn_m16", "conv_korder", "conv_stagger", "attn_pipe", "attn_nomax", "conv_slim2", "conv_korder_mb", "conv_ksplit", "conv_patch", "conv_patch_delay", "fuse_concat", "conv_patch96", "conv_patch_tail", "conv_tail_f32", "conv_src_f32"};
 
 int vh_knob(int id) { return (id >= 0 && id < VH_NUM_KNOBS) ? g_knobs[id] : 0; }

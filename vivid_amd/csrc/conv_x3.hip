@@ -640,9 +640,9 @@ int vh_conv_patch_choice(const vh_conv_args& a, long long M, long long* pwgs_out
     if (a.tile == VH_TILE_PATCH16 && !patch_ok) return -1;
     const long long ptiles = (long long)a.rows * ((a.h + 15) / 16) * ((a.w + 15) / 16);
     const bool tailp = a.src1 != nullptr && !a.src_f32;
-    // fp32 main-loop sources: by default where the kernel has the registers to fetch the next chunk's pieces two K-tiles ahead (64- and 96-channel
-    // blocks: the launch pays ~10 % and the vh_split pass it replaces costs 2.6-2.9x that); 128-channel blocks stage at the boundary, pay the same 10 %
-    // for half the saving per FLOP, and the whole step gains 0.7 % at C2 for 3 % of the convolution family's rate: knob 2 (forced tiles always convert)
+    // fp32 main-loop sources: the launch pays 6-10 % (64- / 96-channel blocks fetch the next chunk's pieces two K-tiles ahead; 128-channel blocks have
+    // no registers for that and load all five at the boundary) and the vh_split pass it replaces costs 2-3x that.  Knob: 2 (default) every block width,
+    // 1 the look-ahead widths only, 0 never (forced tiles always convert)
     if (a.src_f32) {
         const int sk = vh_knob(VH_KNOB_CONV_SRC_F32);
         const bool lookahead = a.cout == 64 || (a.cout % 96 == 0 && a.cout % 128 != 0);

@@ -55,7 +55,7 @@ enum { VH_KNOB_ATTN_XCD = 0, VH_KNOB_DBG_LO = 1, VH_KNOB_DBG_HI = 2, VH_KNOB_ATT
        VH_KNOB_CONV_PATCH_TAIL = 15, // conv_x3_patch with a tail segment: 2 (default) the wave-private register-staged tail, 1 the LDS-DMA staged one (64-channel blocks; A/B)
        VH_KNOB_CONV_TAIL_F32 = 16,   // vh_conv_args.tail_f32 launches: 1 (default) taken where the patch kernel takes tails, 0 never (vh_conv_takes_patch answers 0: callers
                                      // fall back to the raw S8 form of vh_split), 2 also at Cout = 256 / 512 (ties on the S8 tail; A/B)
-       VH_KNOB_CONV_SRC_F32 = 17,    // vh_conv_args.src_f32 launches: 1 (default) 64- / 96-channel blocks (the look-ahead form) under the patch kernel's size rule, 2 every block width,
+       VH_KNOB_CONV_SRC_F32 = 17,    // vh_conv_args.src_f32 launches: 2 (default) every block width under the patch kernel's size rule, 1 the 64- / 96-channel blocks only (the look-ahead form),
                                      // 0 never (vh_conv_takes_patch answers 0: the walks fall back to a vh_split pass and the S8 input)
        VH_NUM_KNOBS = 18 };
 int vh_knob(int id);
